@@ -1,0 +1,173 @@
+/*
+ * ggd_raster.h -- C ABI of the MI355X-native (gfx950) differentiable 3D-Gaussian-splatting rasterizer.
+ *
+ * This is the drop-in boundary for the one hot path of fraunhoferhhi/gaussian_gan_decoder: the native
+ * module `diff_gaussian_rasterization._C` that the reference imports at
+ *   gaussian_splatting/gaussian_renderer/__init__.py:14
+ * and drives through `GaussianRasterizer(...)` at
+ *   gaussian_splatting/gaussian_renderer/__init__.py:53,87-95 (render) and :139,167-175 (render_simple).
+ * The CUDA sources behind that module are an EMPTY, unpinned git submodule in the reference tree
+ * (.gitmodules:4-6); the three pybind entry points it would export are replaced here one-to-one:
+ *
+ *   _C.rasterize_gaussians            ->  ggd_forward_geometry() + ggd_forward_render()
+ *   _C.rasterize_gaussians_backward   ->  ggd_backward()
+ *   _C.mark_visible                   ->  ggd_mark_visible()
+ *
+ * Plain pointers and sizes only; no torch types.  All `const float*` / `void*` tensor arguments are DEVICE
+ * pointers (HIP, gfx950) unless a comment says "host".  `stream` is a hipStream_t passed as void* (NULL = the
+ * default stream).  Every function returns 0 on success or a negative GGD_E_* code; the message is available
+ * through ggd_last_error().  Nothing here throws.
+ *
+ * Buffer ownership mirrors the upstream design (geomBuffer / binningBuffer / imgBuffer byte tensors that the
+ * autograd function keeps alive between forward and backward): the CALLER allocates them with the sizes
+ * returned by ggd_geom_bytes / ggd_binning_bytes / ggd_img_bytes, the library only fills them.  The ctx owns
+ * a grow-only scratch workspace (sort ping-pong space, histograms, block sums, a pinned word for the
+ * `num_rendered` read-back) and is not re-entrant: one ctx per (device, stream).
+ */
+#ifndef GGD_RASTER_H
+#define GGD_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGD_TILE 16 /* tile edge in pixels (16x16), fixed by the algorithm's contract */
+
+enum {
+  GGD_OK = 0,
+  GGD_E_INVALID = -1,   /* bad argument (null pointer, negative size, exactly-one-of rule violated, degree) */
+  GGD_E_HIP = -2,       /* a HIP runtime call failed */
+  GGD_E_NOMEM = -3,     /* workspace allocation failed */
+  GGD_E_PREFILTER = -4, /* prefiltered=1 but a Gaussian failed the frustum test (upstream traps here) */
+  GGD_E_NODEVICE = -5   /* no gfx950 device visible */
+};
+
+typedef struct ggd_ctx ggd_ctx;
+
+/* Per-call parameters == the fields of the reference's GaussianRasterizationSettings
+ * (constructed at gaussian_renderer/__init__.py:38-51 and :124-137) plus tensor extents. */
+typedef struct ggd_params {
+  int32_t P;             /* number of Gaussians */
+  int32_t M;             /* SH coefficients per channel present in `shs` (stride); 0 when colors_precomp is used */
+  int32_t sh_degree;     /* active SH degree D, 0..3 ((D+1)^2 <= M) */
+  int32_t width, height; /* image size in pixels */
+  float tanfovx, tanfovy;
+  float scale_modifier;
+  int32_t prefiltered;
+  int32_t debug;            /* 1: keep a copy of the unsorted key/value list for ggd_debug_unsorted() */
+  const float* viewmatrix;  /* device, 16 floats: world_view_transform flattened row-major (= V^T), cameras.py:85 */
+  const float* projmatrix;  /* device, 16 floats: full_proj_transform flattened row-major (= (P V)^T), cameras.py:91 */
+  const float* campos;      /* device, 3 floats */
+  const float* bg;          /* device, 3 floats */
+} ggd_params;
+
+/* One record per Gaussian, written by the preprocess kernel and gathered by the blend kernels. */
+typedef struct ggd_splat {
+  float x, y;               /* pixel-space centre ("means2D" upstream) */
+  float conA, conB, conC;   /* inverse 2D covariance (conic) */
+  float opacity;
+  float r, g, b;            /* colour after SH evaluation / colors_precomp */
+  float depth;              /* view-space z; its raw bits are the low half of the sort key */
+  int32_t radius;           /* == radii[i] */
+  uint32_t tiles_touched;
+} ggd_splat;                /* 48 bytes */
+
+/* Byte offsets of the named arrays inside the caller-owned buffers (for tests / debug taps / bindings). */
+typedef struct ggd_geom_view {
+  size_t splat;         /* ggd_splat[P] */
+  size_t tiles_touched; /* uint32[P] */
+  size_t point_offsets; /* uint32[P], inclusive prefix sum of tiles_touched */
+  size_t clamped;       /* uint8[P], bit c set <=> colour channel c was clamped at 0 */
+  size_t total;
+} ggd_geom_view;
+
+typedef struct ggd_binning_view {
+  size_t keys;     /* uint64[R] sorted keys:  (tile_id << 32) | depth_bits */
+  size_t list;     /* uint32[R] sorted Gaussian indices ("point_list") */
+  size_t keys_alt; /* uint64[R] ping-pong partner (contents unspecified after the call) */
+  size_t list_alt; /* uint32[R] */
+  size_t total;
+} ggd_binning_view;
+
+typedef struct ggd_img_view {
+  size_t ranges;    /* uint32[2*T]: [first, last) into `list` per tile, (0,0) for empty tiles */
+  size_t final_T;   /* float[H*W] */
+  size_t n_contrib; /* uint32[H*W] */
+  size_t total;
+} ggd_img_view;
+
+size_t ggd_geom_bytes(int32_t P);
+size_t ggd_binning_bytes(int64_t R);
+size_t ggd_img_bytes(int32_t width, int32_t height);
+int ggd_geom_layout(int32_t P, ggd_geom_view* out);
+int ggd_binning_layout(int64_t R, ggd_binning_view* out);
+int ggd_img_layout(int32_t width, int32_t height, ggd_img_view* out);
+
+/* Number of key bits the radix sort covers: 32 + msb(#tiles) (11 for 1024 tiles, 13 for 4096). */
+int ggd_sort_bits(int32_t width, int32_t height);
+
+ggd_ctx* ggd_create(int device);
+void ggd_destroy(ggd_ctx* ctx);
+const char* ggd_last_error(ggd_ctx* ctx); /* ctx may be NULL: returns the last creation error */
+const char* ggd_version(void);
+
+/*
+ * Forward, phase 1 (per Gaussian): frustum cull, cov3D, EWA cov2D, conic, radius, tile rect, SH->RGB;
+ * inclusive scan of tiles_touched; reads the total back ("num_rendered", one host sync on `stream`).
+ * Exactly one of {shs, colors_precomp} and exactly one of {scales+rotations, cov3D_precomp} must be non-NULL.
+ *   means3D[P,3] opacities[P] shs[P,M,3] colors_precomp[P,3] scales[P,3] rotations[P,4](w,x,y,z) cov3D_precomp[P,6]
+ *   geom_buf : ggd_geom_bytes(P) bytes, written     radii : int32[P], written     num_rendered : HOST out
+ */
+int ggd_forward_geometry(ggd_ctx* ctx, void* stream, const ggd_params* prm,
+                         const float* means3D, const float* shs, const float* colors_precomp,
+                         const float* opacities, const float* scales, const float* rotations,
+                         const float* cov3D_precomp,
+                         void* geom_buf, int32_t* radii, int64_t* num_rendered);
+
+/*
+ * Forward, phase 2 (per instance / per tile): duplicateWithKeys, stable radix sort of (tile|depth) keys,
+ * identifyTileRanges, front-to-back alpha blend.  No host sync.
+ *   binning_buf : ggd_binning_bytes(num_rendered)   img_buf : ggd_img_bytes(W,H)   out_color : float[3,H,W]
+ */
+int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* prm,
+                       const void* geom_buf, int64_t num_rendered,
+                       void* binning_buf, void* img_buf, float* out_color);
+
+/*
+ * Backward.  Consumes the three buffers of the matching forward plus the original inputs and dL/d(out_color).
+ * All nine gradient outputs are fully written (zero-filled then accumulated) by the library:
+ *   dL_dmeans2D[P,3] (xy = NDC-scaled screen gradient, z = 0)   dL_dcolors[P,3]   dL_dopacity[P]
+ *   dL_dmeans3D[P,3]   dL_dcov3D[P,6]   dL_dsh[P,M,3] (may be NULL iff M == 0)   dL_dscales[P,3]   dL_drots[P,4]
+ * dL_dconic is internal scratch.
+ */
+int ggd_backward(ggd_ctx* ctx, void* stream, const ggd_params* prm,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* scales, const float* rotations, const float* cov3D_precomp,
+                 const int32_t* radii,
+                 const void* geom_buf, const void* binning_buf, const void* img_buf, int64_t num_rendered,
+                 const float* dL_dpix,
+                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+                 float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots);
+
+/* present[i] = 1 iff Gaussian i passes the view-space z > 0.2 frustum test. */
+int ggd_mark_visible(ggd_ctx* ctx, void* stream, int32_t P, const float* means3D,
+                     const float* viewmatrix, const float* projmatrix, uint8_t* present);
+
+/* Debug tap (prm->debug = 1 on the preceding ggd_forward_render): copies the UNSORTED duplicateWithKeys output
+ * to device buffers keys[R] / values[R] supplied by the caller.  Either pointer may be NULL. */
+int ggd_debug_unsorted(ggd_ctx* ctx, void* stream, uint64_t* keys, uint32_t* values, int64_t num_rendered);
+
+/* Per-stage device time (ms, hipEvent pairs on `stream`) of the most recent forward_geometry / forward_render /
+ * backward call when profiling is on.  Stage names: ggd_stage_name(i), i in [0, ggd_stage_count()). */
+int ggd_set_profiling(ggd_ctx* ctx, int enabled);
+int ggd_stage_count(void);
+const char* ggd_stage_name(int stage);
+int ggd_stage_times(ggd_ctx* ctx, float* ms_out /* host, ggd_stage_count() floats, <0 = not run */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGD_RASTER_H */

@@ -1,0 +1,177 @@
+"""ctypes front-end of the CPU oracle (oracle/ggd_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+(gaussian_gan_decoder_amd) never does.  PARITY UNPINNED: see the header of oracle/ggd_oracle_impl.inc.
+
+Stage-by-stage, every intermediate buffer of SURVEY.md section 8a is returned so the HIP path can be compared
+stage by stage (integers bit-exact, floats within the tolerance written in each test).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libggd_oracle.so")
+
+
+class _Params(C.Structure):
+    _fields_ = [("P", C.c_int32), ("M", C.c_int32), ("D", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+                ("prefiltered", C.c_int32), ("tanfovx", C.c_double), ("tanfovy", C.c_double),
+                ("scale_modifier", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in ("ggd_oracle.c", "ggd_oracle_impl.inc", "Makefile")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B", "libggd_oracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.ggo_scan.restype = C.c_int64
+        _lib.ggo_higher_msb.restype = C.c_uint32
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(np.asarray(a, dtype=dt))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def higher_msb(n: int) -> int:
+    return int(lib().ggo_higher_msb(C.c_uint32(n)))
+
+
+def sort_bits(W: int, H: int) -> int:
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    return 32 + higher_msb(T)
+
+
+def forward(*, means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy,
+            shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+            sh_degree=0, scale_modifier=1.0, prefiltered=False, dtype=np.float32, stop_after=None):
+    """Run all forward stages on the CPU.  Returns a dict of numpy arrays (inputs included)."""
+    L = lib()
+    dt = np.dtype(dtype)
+    suf = "_f32" if dt == np.float32 else "_f64"
+    means3D = _c(means3D, dt, (-1, 3))
+    P = means3D.shape[0]
+    assert (shs is None) != (colors_precomp is None), "exactly one of shs / colors_precomp"
+    assert ((scales is None) and (rotations is None)) != (cov3D_precomp is None), "exactly one of scale+rot / cov3D"
+    opacities = _c(opacities, dt, (-1,))
+    shs = _c(shs, dt)
+    M = 0 if shs is None else shs.reshape(P, -1, 3).shape[1]
+    if shs is not None:
+        shs = shs.reshape(P, M, 3)
+        assert (sh_degree + 1) ** 2 <= M
+    colors_precomp = _c(colors_precomp, dt, (-1, 3))
+    scales = _c(scales, dt, (-1, 3))
+    rotations = _c(rotations, dt, (-1, 4))
+    cov3D_precomp = _c(cov3D_precomp, dt, (-1, 6))
+    view = _c(viewmatrix, dt, (16,))
+    proj = _c(projmatrix, dt, (16,))
+    campos = _c(campos, dt, (3,))
+    bg = _c(bg, dt, (3,))
+    prm = _Params(P, M, int(sh_degree), int(W), int(H), int(bool(prefiltered)),
+                  float(np.float32(tanfovx)) if dt == np.float32 else float(tanfovx),
+                  float(np.float32(tanfovy)) if dt == np.float32 else float(tanfovy),
+                  float(np.float32(scale_modifier)) if dt == np.float32 else float(scale_modifier))
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    T = gx * gy
+    out = dict(P=P, M=M, W=W, H=H, T=T, dtype=dt, sh_degree=int(sh_degree), prm=prm,
+               means3D=means3D, opacities=opacities, shs=shs, colors_precomp=colors_precomp, scales=scales,
+               rotations=rotations, cov3D_precomp=cov3D_precomp, viewmatrix=view, projmatrix=proj, campos=campos,
+               bg=bg)
+    depths = np.zeros(P, dt); radii = np.zeros(P, np.int32); xy = np.zeros((P, 2), dt)
+    cov3D = np.zeros((P, 6), dt); conic_opacity = np.zeros((P, 4), dt); rgb = np.zeros((P, 3), dt)
+    tiles_touched = np.zeros(P, np.uint32); clamped = np.zeros((P, 3), np.uint8); rect = np.zeros((P, 4), np.int32)
+    rc = getattr(L, "ggo_preprocess" + suf)(C.byref(prm), _p(view), _p(proj), _p(campos), _p(means3D), _p(shs),
+                                            _p(colors_precomp), _p(opacities), _p(scales), _p(rotations),
+                                            _p(cov3D_precomp), _p(depths), _p(radii), _p(xy), _p(cov3D),
+                                            _p(conic_opacity), _p(rgb), _p(tiles_touched), _p(clamped), _p(rect))
+    if rc != 0:
+        raise RuntimeError(f"oracle preprocess failed rc={rc} (prefiltered point culled)")
+    out.update(depths=depths, radii=radii, xy=xy, cov3D=cov3D, conic_opacity=conic_opacity, rgb=rgb,
+               tiles_touched=tiles_touched, clamped=clamped, rect=rect)
+    offsets = np.zeros(P, np.uint32)
+    R = int(L.ggo_scan(P, _p(tiles_touched), _p(offsets)))
+    out.update(point_offsets=offsets, num_rendered=R)
+    if stop_after == "scan":
+        return out
+    keys_u = np.zeros(R, np.uint64); vals_u = np.zeros(R, np.uint32)
+    getattr(L, "ggo_duplicate" + suf)(P, W, _p(radii), _p(rect), _p(depths), _p(offsets), _p(keys_u), _p(vals_u))
+    keys = np.zeros(R, np.uint64); vals = np.zeros(R, np.uint32)
+    nbits = sort_bits(W, H)
+    rc = L.ggo_sort_pairs(C.c_int64(R), _p(keys_u), _p(vals_u), _p(keys), _p(vals), nbits)
+    assert rc == 0
+    ranges = np.zeros((T, 2), np.uint32)
+    L.ggo_tile_ranges(C.c_int64(R), _p(keys), T, _p(ranges))
+    out.update(keys_unsorted=keys_u, list_unsorted=vals_u, keys=keys, point_list=vals, ranges=ranges,
+               sort_bits=nbits)
+    if stop_after == "binning":
+        return out
+    color = np.zeros((3, H, W), dt); final_T = np.zeros((H, W), dt); n_contrib = np.zeros((H, W), np.uint32)
+    getattr(L, "ggo_render" + suf)(C.byref(prm), _p(bg), _p(ranges), _p(vals), _p(xy), _p(conic_opacity), _p(rgb),
+                                   _p(color), _p(final_T), _p(n_contrib))
+    out.update(color=color, final_T=final_T, n_contrib=n_contrib)
+    return out
+
+
+def backward(fwd: dict, dL_dpix):
+    """Backward stages a10 + a11 on the CPU.  `fwd` is the dict returned by forward()."""
+    L = lib()
+    dt = fwd["dtype"]
+    suf = "_f32" if dt == np.float32 else "_f64"
+    P, M, W, H = fwd["P"], fwd["M"], fwd["W"], fwd["H"]
+    prm = fwd["prm"]
+    g = _c(dL_dpix, dt, (3, H, W))
+    d_mean2D = np.zeros((P, 2), np.float64); d_conic = np.zeros((P, 3), np.float64)
+    d_opacity = np.zeros(P, np.float64); d_colors = np.zeros((P, 3), np.float64)
+    getattr(L, "ggo_render_backward" + suf)(C.byref(prm), _p(fwd["bg"]), _p(fwd["ranges"]), _p(fwd["point_list"]),
+                                            _p(fwd["xy"]), _p(fwd["conic_opacity"]), _p(fwd["rgb"]),
+                                            _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(g),
+                                            _p(d_mean2D), _p(d_conic), _p(d_opacity), _p(d_colors))
+    m2 = d_mean2D.astype(dt); co = d_conic.astype(dt); dc = d_colors.astype(dt)
+    d_means3D = np.zeros((P, 3), dt); d_cov3D = np.zeros((P, 6), dt)
+    d_sh = np.zeros((P, max(M, 1), 3), dt) if M > 0 else None
+    d_scales = np.zeros((P, 3), dt); d_rots = np.zeros((P, 4), dt)
+    have_cp = fwd["colors_precomp"] is not None
+    have_c3 = fwd["cov3D_precomp"] is not None
+    getattr(L, "ggo_preprocess_backward" + suf)(
+        C.byref(prm), _p(fwd["viewmatrix"]), _p(fwd["projmatrix"]), _p(fwd["campos"]), _p(fwd["means3D"]),
+        _p(fwd["shs"]), int(have_cp), _p(fwd["scales"]), _p(fwd["rotations"]), _p(fwd["cov3D"]), int(have_c3),
+        _p(fwd["radii"]), _p(fwd["clamped"]), _p(m2), _p(co), _p(dc),
+        _p(d_means3D), _p(d_cov3D), _p(d_sh), _p(d_scales), _p(d_rots))
+    d_means2D = np.zeros((P, 3), dt)
+    d_means2D[:, :2] = m2
+    return dict(dL_dmeans2D=d_means2D, dL_dconic=co, dL_dopacity=d_opacity.astype(dt), dL_dcolors=dc,
+                dL_dmeans3D=d_means3D, dL_dcov3D=d_cov3D, dL_dsh=d_sh, dL_dscales=d_scales, dL_drots=d_rots)
+
+
+def mark_visible(means3D, viewmatrix):
+    L = lib()
+    m = _c(means3D, np.float32, (-1, 3)); v = _c(viewmatrix, np.float32, (16,))
+    out = np.zeros(m.shape[0], np.uint8)
+    L.ggo_mark_visible(m.shape[0], _p(m), _p(v), _p(out))
+    return out.astype(bool)
