@@ -1,0 +1,149 @@
+"""ctypes binding of libggd_raster.so (C ABI: include/ggd_raster.h).
+
+Raw device pointers + the current HIP stream handle cross the boundary; torch only provides memory and streams.
+The library is required: if it is missing or fails to load, importing the rasterizer raises -- there is NO CPU
+or eager fallback in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libggd_raster.so")
+
+EXPORTS = [
+    "ggd_geom_bytes", "ggd_binning_bytes", "ggd_img_bytes", "ggd_geom_layout", "ggd_binning_layout",
+    "ggd_img_layout", "ggd_sort_bits", "ggd_create", "ggd_destroy", "ggd_last_error", "ggd_version",
+    "ggd_forward_geometry", "ggd_forward_render", "ggd_backward", "ggd_mark_visible", "ggd_debug_unsorted",
+    "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("P", C.c_int32), ("M", C.c_int32), ("sh_degree", C.c_int32), ("width", C.c_int32),
+                ("height", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("scale_modifier", C.c_float), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+                ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+                ("bg", C.c_void_p)]
+
+
+class GeomView(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("splat", "tiles_touched", "point_offsets", "clamped", "total")]
+
+
+class BinningView(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("keys", "list", "keys_alt", "list_alt", "total")]
+
+
+class ImgView(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("ranges", "final_T", "n_contrib", "total")]
+
+
+SPLAT_BYTES = 48
+SPLAT_FIELDS = ("x", "y", "conA", "conB", "conC", "opacity", "r", "g", "b", "depth", "radius", "tiles_touched")
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load the shared library (after torch, so both share one HIP runtime).  Raises if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m gaussian_gan_decoder_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the rasterizer.")
+        import torch  # noqa: F401  (loads torch's libamdhip64 first; our NEEDED entry then binds to the same runtime)
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+        lib.ggd_geom_bytes.restype = sz; lib.ggd_geom_bytes.argtypes = [i32]
+        lib.ggd_binning_bytes.restype = sz; lib.ggd_binning_bytes.argtypes = [i64]
+        lib.ggd_img_bytes.restype = sz; lib.ggd_img_bytes.argtypes = [i32, i32]
+        lib.ggd_geom_layout.argtypes = [i32, C.POINTER(GeomView)]
+        lib.ggd_binning_layout.argtypes = [i64, C.POINTER(BinningView)]
+        lib.ggd_img_layout.argtypes = [i32, i32, C.POINTER(ImgView)]
+        lib.ggd_sort_bits.argtypes = [i32, i32]
+        lib.ggd_create.restype = vp; lib.ggd_create.argtypes = [C.c_int]
+        lib.ggd_destroy.restype = None; lib.ggd_destroy.argtypes = [vp]
+        lib.ggd_last_error.restype = C.c_char_p; lib.ggd_last_error.argtypes = [vp]
+        lib.ggd_version.restype = C.c_char_p
+        lib.ggd_forward_geometry.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 7 + [vp, vp, C.POINTER(i64)]
+        lib.ggd_forward_render.argtypes = [vp, vp, C.POINTER(Params), vp, i64, vp, vp, vp]
+        lib.ggd_backward.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 6 + [vp, vp, vp, vp, i64, vp] + [vp] * 8
+        lib.ggd_mark_visible.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+        lib.ggd_debug_unsorted.argtypes = [vp, vp, vp, vp, i64]
+        lib.ggd_set_profiling.argtypes = [vp, C.c_int]
+        lib.ggd_stage_name.restype = C.c_char_p; lib.ggd_stage_name.argtypes = [C.c_int]
+        lib.ggd_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
+        _lib = lib
+        return lib
+
+
+class RasterError(RuntimeError):
+    pass
+
+
+class Context:
+    """One ggd_ctx (device workspace); not re-entrant, use one per (device, stream)."""
+
+    def __init__(self, device_index: int):
+        self.lib = load()
+        self.device_index = int(device_index)
+        self.handle = self.lib.ggd_create(self.device_index)
+        if not self.handle:
+            raise RasterError("ggd_create failed: " + self.lib.ggd_last_error(None).decode())
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise RasterError(f"ggd error {rc}: " + self.lib.ggd_last_error(self.handle).decode())
+
+    def set_profiling(self, on: bool):
+        self.check(self.lib.ggd_set_profiling(self.handle, int(bool(on))))
+
+    def stage_times(self) -> dict:
+        n = self.lib.ggd_stage_count()
+        arr = (C.c_float * n)()
+        self.check(self.lib.ggd_stage_times(self.handle, arr))
+        return {self.lib.ggd_stage_name(i).decode(): float(arr[i]) for i in range(n) if arr[i] >= 0}
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ggd_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts: dict = {}
+
+
+def context_for(device) -> Context:
+    """Per-(device, stream) context cache."""
+    import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, int(torch.cuda.current_stream(idx).cuda_stream))
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = _contexts[key] = Context(idx)
+    return ctx
+
+
+def geom_view(P: int) -> GeomView:
+    v = GeomView(); load().ggd_geom_layout(P, C.byref(v)); return v
+
+
+def binning_view(R: int) -> BinningView:
+    v = BinningView(); load().ggd_binning_layout(R, C.byref(v)); return v
+
+
+def img_view(W: int, H: int) -> ImgView:
+    v = ImgView(); load().ggd_img_layout(W, H, C.byref(v)); return v

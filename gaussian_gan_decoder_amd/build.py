@@ -1,0 +1,70 @@
+"""Build the gfx950 rasterizer library (libggd_raster.so) in-tree with hipcc.
+
+    python -m gaussian_gan_decoder_amd.build [--force] [--save-temps]
+
+hipcc cross-compiles for gfx950 without a GPU.  Flags that are part of the numerical contract:
+  -ffp-contract=off                              no implicit FMA contraction (integer anchors bit-exact vs oracle)
+  -fhip-fp32-correctly-rounded-divide-sqrt       IEEE division / sqrt
+  -munsafe-fp-atomics                            float atomicAdd -> global_atomic_add_f32 (no CAS loop)
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+CSRC = os.path.join(_PKG, "csrc")
+LIB_PATH = os.path.join(_PKG, "libggd_raster.so")
+SOURCES = ["ggd_capi.hip", "ggd_preprocess.hip", "ggd_binning.hip", "ggd_blend.hip", "ggd_preprocess_bwd.hip"]
+HEADERS = ["ggd_common.h", "ggd_math.h"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0 to build the gfx950 rasterizer)")
+
+
+def flags() -> list[str]:
+    return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+            "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics", "-fno-gpu-rdc",
+            "-Wall", "-Wno-unused-function", "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC]
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(_ROOT, "include", "ggd_raster.h"),
+                                                                 os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, save_temps: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [_hipcc()] + flags() + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB_PATH]
+    cwd = CSRC
+    if save_temps:
+        tmp = os.path.join(_ROOT, "gpurun_out", "temps")
+        os.makedirs(tmp, exist_ok=True)
+        cmd.insert(1, "-save-temps")
+        cwd = tmp
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    if verbose and res.stderr.strip():
+        print(res.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True)
+    print("built", p)

@@ -1,0 +1,373 @@
+// ggd_binning.hip -- stages a5 (inclusive scan), a6 (duplicateWithKeys), a7 (stable radix sort), a8 (tile ranges).
+//
+// Integer-only, HBM-bound work; every result here is bit-exact by contract.  The reference
+// reaches these stages inside `_C.rasterize_gaussians` (gaussian_renderer/__init__.py:167-175); upstream uses
+// cub::DeviceScan / cub::DeviceRadixSort, here they are hand-written for wave64:
+//   * scan: two-level (per-block reduce -> one block scans the block sums -> per-block scan+offset);
+//   * duplicate: the 256 Gaussians of a block pool their instances and emit them with consecutive lanes writing
+//     consecutive instances (coalesced 8 B + 4 B stores) instead of one divergent per-Gaussian loop each;
+//   * sort: LSD radix, 8-bit digits over key bits [0, 32+msb(T)), stable by construction: per-block digit
+//     histograms -> exclusive scan in (digit, block) order -> per-block ranking with wave64 ballot matching
+//     (rank inside a wave = popcount of lower peer lanes), scatter.  Keys embed raw fp32 depth bits, so the
+//     sorted order (ties included) is identical to a stable sort of the emission order.
+#include "ggd_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ block scan --
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;                        // per thread
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 per block
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// Exclusive prefix of `v` over the 256 threads of the block (4 waves); *total = block sum.
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* total, uint32_t* lds4) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t inc = wave_inclusive_scan(v);
+  if (lane == 63) lds4[wv] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t s = lds4[w];
+    if (w < wv) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in, int64_t n,
+                                                                   uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t lds4[4];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t s = 0;
+  if (base + SCAN_ITEMS <= n) {
+    const uint4 a = *reinterpret_cast<const uint4*>(in + base);
+    const uint4 b = *reinterpret_cast<const uint4*>(in + base + 4);
+    s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+  } else {
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+      if (base + k < n) s += in[base + k];
+  }
+  uint32_t tot;
+  block_exclusive_scan_256(s, &tot, lds4);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// One block turns block_sums[nb] into exclusive block prefixes (in place) and writes the grand total.
+__global__ __launch_bounds__(SCAN_THREADS) void scan_blocksums_kernel(uint32_t* __restrict__ block_sums, int nb,
+                                                                      uint32_t* __restrict__ d_total) {
+  __shared__ uint32_t lds4[4];
+  uint32_t carry = 0;
+  for (int start = 0; start < nb; start += SCAN_THREADS) {
+    const int i = start + threadIdx.x;
+    const uint32_t v = i < nb ? block_sums[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan_256(v, &tot, lds4);
+    if (i < nb) block_sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && d_total) *d_total = carry;
+}
+
+template <bool EXCLUSIVE>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t* __restrict__ in,
+                                                                  uint32_t* __restrict__ out, int64_t n,
+                                                                  const uint32_t* __restrict__ block_prefix) {
+  __shared__ uint32_t lds4[4];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  const bool full = base + SCAN_ITEMS <= n;
+  if (full) {
+    const uint4 a = *reinterpret_cast<const uint4*>(in + base);
+    const uint4 b = *reinterpret_cast<const uint4*>(in + base + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = (base + k < n) ? in[base + k] : 0u;
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) s += v[k];
+  uint32_t tot;
+  uint32_t run = block_exclusive_scan_256(s, &tot, lds4) + block_prefix[blockIdx.x];
+  uint32_t o[SCAN_ITEMS];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    if (EXCLUSIVE) { o[k] = run; run += v[k]; } else { run += v[k]; o[k] = run; }
+  }
+  if (full) {
+    *reinterpret_cast<uint4*>(out + base) = make_uint4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint4*>(out + base + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+      if (base + k < n) out[base + k] = o[k];
+  }
+}
+
+template <bool EXCLUSIVE>
+int launch_scan(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, uint32_t* out, int64_t n, uint32_t* d_total,
+                void* tmp, size_t tmp_bytes) {
+  if (n <= 0) {
+    if (d_total) GGD_HIP(hipMemsetAsync(d_total, 0, sizeof(uint32_t), s));
+    return GGD_OK;
+  }
+  const int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+  if (tmp_bytes < (size_t)nb * sizeof(uint32_t)) return ggd_fail(ctx, GGD_E_INVALID, "scan tmp too small");
+  uint32_t* block_sums = static_cast<uint32_t*>(tmp);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, block_sums);
+  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, block_sums, nb, d_total);
+  hipLaunchKernelGGL(scan_apply_kernel<EXCLUSIVE>, dim3(nb), dim3(SCAN_THREADS), 0, s, in, out, n, block_sums);
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- duplicate --
+// 256 Gaussians per block.  LDS holds, per Gaussian of the block, the block-local exclusive instance offset,
+// the tile rect origin/width and the depth bits; lanes then walk the block's pooled instance list.
+__global__ __launch_bounds__(256) void duplicate_kernel(int P, int W, int H, const ggd_splat* __restrict__ splat,
+                                                        const uint32_t* __restrict__ tiles_touched,
+                                                        const uint32_t* __restrict__ offsets,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  __shared__ uint32_t s_excl[257];
+  __shared__ uint32_t s_origin[256];  // minx | miny << 16
+  __shared__ uint32_t s_width[256];
+  __shared__ uint32_t s_depth[256];
+  __shared__ uint32_t s_base;
+  const int tid = threadIdx.x;
+  const int first = blockIdx.x * 256;
+  const int i = first + tid;
+  uint32_t nt = 0, inc = 0;
+  if (i < P) { nt = tiles_touched[i]; inc = offsets[i]; }
+  const uint32_t excl = inc - nt;
+  if (tid == 0) s_base = excl;
+  const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+  uint32_t origin = 0, width = 1, dbits = 0;
+  if (nt > 0) {
+    const float4 a = reinterpret_cast<const float4*>(splat + i)[0];  // x, y, conA, conB
+    const float4 c = reinterpret_cast<const float4*>(splat + i)[2];  // b, depth, radius, tiles
+    int minx, miny, maxx, maxy;
+    ggd_tile_rect(a.x, a.y, __float_as_int(c.z), gx, gy, minx, miny, maxx, maxy);
+    origin = (uint32_t)minx | ((uint32_t)miny << 16);
+    width = (uint32_t)(maxx - minx);
+    dbits = __float_as_uint(c.y);
+  }
+  __syncthreads();
+  const uint32_t base = s_base;
+  s_excl[tid] = excl - base;
+  s_origin[tid] = origin; s_width[tid] = width; s_depth[tid] = dbits;
+  // block total = inclusive offset of the last valid Gaussian of the block - base
+  const int last = min(P, first + 256) - 1 - first;
+  if (tid == last) s_excl[256] = inc - base;
+  __syncthreads();
+  const uint32_t total = s_excl[256];
+  if (tid > last) s_excl[tid] = total;  // padding entries (only when the block is ragged) never match
+  __syncthreads();
+  for (uint32_t j = tid; j < total; j += 256) {
+    // largest g in [0,256) with s_excl[g] <= j  (entries are non-decreasing)
+    int lo = 0;
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1) {
+      const int probe = lo + step;
+      if (probe < 256 && s_excl[probe] <= j) lo = probe;
+    }
+    // s_excl may hold runs of equal values (Gaussians with zero tiles): the LAST of a run owns instance j only
+    // if it has tiles; the search above already returns the last index with excl <= j, which is the owner.
+    const uint32_t k = j - s_excl[lo];
+    const uint32_t w = s_width[lo];
+    const uint32_t ry = k / w, rx = k - ry * w;
+    const uint32_t org = s_origin[lo];
+    const uint32_t tile = ((org >> 16) + ry) * (uint32_t)gx + (org & 0xffffu) + rx;
+    const size_t dst = (size_t)base + j;
+    keys[dst] = ((uint64_t)tile << 32) | (uint64_t)s_depth[lo];
+    vals[dst] = (uint32_t)(first + lo);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- radix sort ---
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 16;                      // keys per lane
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;    // 4096 pairs per block
+constexpr int RS_WAVE_TILE = 64 * RS_ITEMS;       // 1024 consecutive pairs per wave
+constexpr int RS_BINS = 256;
+
+// hist[digit * nblk + blk] = number of keys of block `blk` whose digit (bits [shift, shift+8)) equals `digit`.
+__global__ __launch_bounds__(RS_THREADS) void sort_hist_kernel(const uint64_t* __restrict__ keys, int64_t n,
+                                                               int shift, uint32_t* __restrict__ hist, int nblk) {
+  __shared__ uint32_t s_hist[RS_BINS];
+  s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+  for (int k = 0; k < RS_ITEMS; ++k) {
+    const int64_t idx = base + (int64_t)k * RS_THREADS + threadIdx.x;
+    if (idx < n) atomicAdd(&s_hist[(uint32_t)(keys[idx] >> shift) & 0xffu], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+// Stable scatter.  Element order inside a block = (wave, round, lane): wave w owns the contiguous 1024 pairs
+// [blk*4096 + w*1024, +1024) and visits them 64 at a time, lane l <-> element round*64 + l.
+__global__ __launch_bounds__(RS_THREADS) void sort_scatter_kernel(const uint64_t* __restrict__ keys_in,
+                                                                  const uint32_t* __restrict__ vals_in,
+                                                                  uint64_t* __restrict__ keys_out,
+                                                                  uint32_t* __restrict__ vals_out, int64_t n,
+                                                                  int shift, const uint32_t* __restrict__ hist_ex,
+                                                                  int nblk) {
+  __shared__ uint32_t s_cnt[4][RS_BINS];   // per-wave running digit counts -> per-wave exclusive bases
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int b = threadIdx.x; b < 4 * RS_BINS; b += RS_THREADS) (&s_cnt[0][0])[b] = 0;
+  __syncthreads();
+
+  const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)wv * RS_WAVE_TILE;
+  uint64_t key[RS_ITEMS];
+  uint32_t val[RS_ITEMS];
+  uint32_t rank[RS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    const int64_t idx = wbase + r * 64 + lane;
+    const bool ok = idx < n;
+    key[r] = ok ? keys_in[idx] : ~0ull;
+    val[r] = ok ? vals_in[idx] : 0u;
+  }
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    const int64_t idx = wbase + r * 64 + lane;
+    const bool ok = idx < n;
+    const uint32_t d = (uint32_t)(key[r] >> shift) & 0xffu;
+    uint64_t peers = __ballot(ok);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const uint64_t m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const uint32_t before = s_cnt[wv][d];  // all peers read the same word (LDS broadcast)
+    const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
+    rank[r] = before + below;
+    // wave-synchronous: every peer has read `before` before the leader updates it (same instruction stream)
+    __builtin_amdgcn_wave_barrier();
+    if (ok && below == 0) s_cnt[wv][d] = before + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // per digit: turn the 4 per-wave totals into exclusive bases and add the global (digit, block) offset
+  {
+    const int d = threadIdx.x;
+    uint32_t run = hist_ex[(size_t)d * nblk + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t c = s_cnt[w][d];
+      s_cnt[w][d] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; ++r) {
+    const int64_t idx = wbase + r * 64 + lane;
+    if (idx < n) {
+      const uint32_t d = (uint32_t)(key[r] >> shift) & 0xffu;
+      const size_t dst = (size_t)s_cnt[wv][d] + rank[r];
+      keys_out[dst] = key[r];
+      vals_out[dst] = val[r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- tile ranges -----
+__global__ __launch_bounds__(256) void ranges_kernel(const uint64_t* __restrict__ keys, int64_t n,
+                                                     uint32_t* __restrict__ ranges) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t tile = (uint32_t)(keys[i] >> 32);
+  if (i == 0) {
+    ranges[2 * tile] = 0;
+  } else {
+    const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
+    if (prev != tile) {
+      ranges[2 * prev + 1] = (uint32_t)i;
+      ranges[2 * tile] = (uint32_t)i;
+    }
+  }
+  if (i == n - 1) ranges[2 * tile + 1] = (uint32_t)n;
+}
+
+}  // namespace
+
+size_t ggd_scan_tmp_bytes(int64_t n) {
+  const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  return ggd_align((size_t)(nb > 0 ? nb : 1) * sizeof(uint32_t));
+}
+
+int ggd_launch_inclusive_scan(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, uint32_t* out, int64_t n,
+                              uint32_t* d_total, void* tmp, size_t tmp_bytes) {
+  return launch_scan<false>(ctx, s, in, out, n, d_total, tmp, tmp_bytes);
+}
+
+int ggd_launch_duplicate(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
+                         const uint32_t* tiles_touched, const uint32_t* offsets, uint64_t* keys, uint32_t* vals) {
+  if (prm.P == 0) return GGD_OK;
+  hipLaunchKernelGGL(duplicate_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, s, prm.P, prm.width, prm.height,
+                     splat, tiles_touched, offsets, keys, vals);
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
+static inline int sort_passes(int nbits) { return (nbits + 7) / 8; }
+int ggd_sort_input_is_alt(int nbits) { return sort_passes(nbits) & 1; }
+
+size_t ggd_sort_tmp_bytes(int64_t n) {
+  const int64_t nblk = (n + RS_TILE - 1) / RS_TILE;
+  const int64_t cnt = (nblk > 0 ? nblk : 1) * RS_BINS;
+  return ggd_align((size_t)cnt * sizeof(uint32_t)) + ggd_scan_tmp_bytes(cnt);
+}
+
+int ggd_launch_sort(ggd_ctx* ctx, hipStream_t s, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b,
+                    uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes) {
+  if (n <= 0) return GGD_OK;
+  if (tmp_bytes < ggd_sort_tmp_bytes(n)) return ggd_fail(ctx, GGD_E_INVALID, "sort tmp too small");
+  const int nblk = (int)((n + RS_TILE - 1) / RS_TILE);
+  const int64_t cnt = (int64_t)nblk * RS_BINS;
+  uint32_t* hist = static_cast<uint32_t*>(tmp);
+  void* scan_tmp = static_cast<char*>(tmp) + ggd_align((size_t)cnt * sizeof(uint32_t));
+  const size_t scan_tmp_bytes = ggd_scan_tmp_bytes(cnt);
+  const int passes = sort_passes(nbits);
+  uint64_t* kin = (passes & 1) ? keys_b : keys_a;
+  uint32_t* vin = (passes & 1) ? vals_b : vals_a;
+  uint64_t* kout = (passes & 1) ? keys_a : keys_b;
+  uint32_t* vout = (passes & 1) ? vals_a : vals_b;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 8 * p;
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, kin, n, shift, hist, nblk);
+    const int rc = launch_scan<true>(ctx, s, hist, hist, cnt, nullptr, scan_tmp, scan_tmp_bytes);
+    if (rc != GGD_OK) return rc;
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift,
+                       hist, nblk);
+    uint64_t* tk = kin; kin = kout; kout = tk;
+    uint32_t* tv = vin; vin = vout; vout = tv;
+  }
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
+int ggd_launch_ranges(ggd_ctx* ctx, hipStream_t s, const uint64_t* keys, int64_t n, uint32_t* ranges, int T) {
+  GGD_HIP(hipMemsetAsync(ranges, 0, (size_t)T * 2 * sizeof(uint32_t), s));
+  if (n <= 0) return GGD_OK;
+  hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, n, ranges);
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}

@@ -1,0 +1,373 @@
+// ggd_capi.hip -- the C ABI declared in include/ggd_raster.h (host side: ctx, workspace, stage sequencing).
+//
+// Stage sequence of one forward: preprocess -> inclusive scan -> read back R ->
+// duplicateWithKeys -> stable radix sort -> tile ranges -> blend.  The one host sync is the read-back of
+// R = num_rendered, exactly where the CUDA original has it; everything else is enqueued on the caller's stream.
+#include <string.h>
+
+#include <new>
+
+#include "ggd_common.h"
+
+static std::string g_create_error;
+
+static const char* const kStageNames[ST_COUNT] = {"preprocess", "scan", "readback", "duplicate", "sort",
+                                                  "ranges", "blend", "blend_bwd", "preprocess_bwd"};
+
+int ggd_fail(ggd_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg; else g_create_error = msg;
+  return code;
+}
+
+int ggd_reserve_scratch(ggd_ctx* ctx, size_t bytes, hipStream_t stream) {
+  if (bytes <= ctx->scratch_bytes) return GGD_OK;
+  // grow-only with head-room so steady-state training never reallocates
+  size_t want = bytes + bytes / 4 + (1u << 20);
+  if (ctx->scratch) {
+    GGD_HIP(hipStreamSynchronize(stream));
+    GGD_HIP(hipFree(ctx->scratch));
+    ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+  }
+  hipError_t e = hipMalloc(&ctx->scratch, want);
+  if (e != hipSuccess) return ggd_fail(ctx, GGD_E_NOMEM, std::string("hipMalloc scratch: ") + hipGetErrorString(e));
+  ctx->scratch_bytes = want;
+  return GGD_OK;
+}
+
+// ---- layouts -------------------------------------------------------------------------------------------------
+extern "C" int ggd_geom_layout(int32_t P, ggd_geom_view* v) {
+  if (!v || P < 0) return GGD_E_INVALID;
+  size_t off = 0;
+  v->splat = off; off += ggd_align((size_t)P * sizeof(ggd_splat));
+  v->tiles_touched = off; off += ggd_align((size_t)P * sizeof(uint32_t));
+  v->point_offsets = off; off += ggd_align((size_t)P * sizeof(uint32_t));
+  v->clamped = off; off += ggd_align((size_t)P);
+  v->total = off;
+  return GGD_OK;
+}
+extern "C" int ggd_binning_layout(int64_t R, ggd_binning_view* v) {
+  if (!v || R < 0) return GGD_E_INVALID;
+  size_t off = 0;
+  v->keys = off; off += ggd_align((size_t)R * sizeof(uint64_t));
+  v->list = off; off += ggd_align((size_t)R * sizeof(uint32_t));
+  v->keys_alt = off; off += ggd_align((size_t)R * sizeof(uint64_t));
+  v->list_alt = off; off += ggd_align((size_t)R * sizeof(uint32_t));
+  v->total = off;
+  return GGD_OK;
+}
+extern "C" int ggd_img_layout(int32_t W, int32_t H, ggd_img_view* v) {
+  if (!v || W < 0 || H < 0) return GGD_E_INVALID;
+  const size_t T = (size_t)((W + 15) / 16) * ((H + 15) / 16);
+  size_t off = 0;
+  v->ranges = off; off += ggd_align(T * 2 * sizeof(uint32_t));
+  v->final_T = off; off += ggd_align((size_t)W * H * sizeof(float));
+  v->n_contrib = off; off += ggd_align((size_t)W * H * sizeof(uint32_t));
+  v->total = off;
+  return GGD_OK;
+}
+extern "C" size_t ggd_geom_bytes(int32_t P) { ggd_geom_view v; return ggd_geom_layout(P, &v) == GGD_OK ? v.total : 0; }
+extern "C" size_t ggd_binning_bytes(int64_t R) { ggd_binning_view v; return ggd_binning_layout(R, &v) == GGD_OK ? v.total : 0; }
+extern "C" size_t ggd_img_bytes(int32_t W, int32_t H) { ggd_img_view v; return ggd_img_layout(W, H, &v) == GGD_OK ? v.total : 0; }
+
+static uint32_t higher_msb(uint32_t n) {  // smallest k with (n >> k) == 0, by bisection from 16
+  uint32_t msb = 16, step = 16;
+  while (step > 1) {
+    step /= 2;
+    if (n >> msb) msb += step; else msb -= step;
+  }
+  if (n >> msb) msb++;
+  return msb;
+}
+extern "C" int ggd_sort_bits(int32_t W, int32_t H) {
+  const uint32_t T = (uint32_t)((W + 15) / 16) * (uint32_t)((H + 15) / 16);
+  return 32 + (int)higher_msb(T);
+}
+
+// ---- ctx -----------------------------------------------------------------------------------------------------
+extern "C" const char* ggd_version(void) { return "ggd-raster 0.1 (gfx950)"; }
+extern "C" int ggd_stage_count(void) { return ST_COUNT; }
+extern "C" const char* ggd_stage_name(int s) { return (s >= 0 && s < ST_COUNT) ? kStageNames[s] : ""; }
+
+extern "C" ggd_ctx* ggd_create(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    ggd_fail(nullptr, GGD_E_NODEVICE, "no HIP device " + std::to_string(device) + " visible");
+    return nullptr;
+  }
+  ggd_ctx* ctx = new (std::nothrow) ggd_ctx();
+  if (!ctx) { ggd_fail(nullptr, GGD_E_NOMEM, "out of host memory"); return nullptr; }
+  ctx->device = device;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  bool ok = hipSetDevice(device) == hipSuccess &&
+            hipMalloc((void**)&ctx->d_words, 64) == hipSuccess &&
+            hipHostMalloc((void**)&ctx->h_words, 64, hipHostMallocDefault) == hipSuccess &&
+            hipMemset(ctx->d_words, 0, 64) == hipSuccess;
+  for (int i = 0; ok && i < 2 * ST_COUNT; ++i) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
+  (void)hipSetDevice(prev);
+  if (!ok) {
+    ggd_fail(nullptr, GGD_E_HIP, std::string("ggd_create: ") + hipGetErrorString(hipGetLastError()));
+    ggd_destroy(ctx);
+    return nullptr;
+  }
+  return ctx;
+}
+
+extern "C" void ggd_destroy(ggd_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->d_words) (void)hipFree(ctx->d_words);
+  if (ctx->h_words) (void)hipHostFree(ctx->h_words);
+  if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);
+  if (ctx->dbg_vals) (void)hipFree(ctx->dbg_vals);
+  for (int i = 0; i < 2 * ST_COUNT; ++i)
+    if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  delete ctx;
+}
+
+extern "C" const char* ggd_last_error(ggd_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int ggd_set_profiling(ggd_ctx* ctx, int enabled) {
+  if (!ctx) return GGD_E_INVALID;
+  ctx->profiling = enabled != 0;
+  for (int i = 0; i < ST_COUNT; ++i) ctx->ev_used[i] = false;
+  return GGD_OK;
+}
+
+extern "C" int ggd_stage_times(ggd_ctx* ctx, float* ms_out) {
+  if (!ctx || !ms_out) return GGD_E_INVALID;
+  for (int i = 0; i < ST_COUNT; ++i) {
+    ms_out[i] = -1.0f;
+    if (ctx->ev_used[i]) {
+      GGD_HIP(hipEventSynchronize(ctx->ev[2 * i + 1]));
+      float ms = 0.0f;
+      GGD_HIP(hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
+      ms_out[i] = ms;
+    }
+  }
+  return GGD_OK;
+}
+
+static int check_params(ggd_ctx* ctx, const ggd_params* prm) {
+  if (!ctx) return GGD_E_INVALID;
+  if (!prm) return ggd_fail(ctx, GGD_E_INVALID, "params is NULL");
+  if (prm->P < 0 || prm->width <= 0 || prm->height <= 0)
+    return ggd_fail(ctx, GGD_E_INVALID, "bad P / image size");
+  if (!prm->viewmatrix || !prm->projmatrix || !prm->campos || !prm->bg)
+    return ggd_fail(ctx, GGD_E_INVALID, "viewmatrix / projmatrix / campos / bg must be device pointers");
+  if (prm->sh_degree < 0 || prm->sh_degree > 3) return ggd_fail(ctx, GGD_E_INVALID, "sh_degree must be 0..3");
+  if (prm->tanfovx == 0.0f || prm->tanfovy == 0.0f) return ggd_fail(ctx, GGD_E_INVALID, "tanfov must be non-zero");
+  return GGD_OK;
+}
+
+static int check_inputs(ggd_ctx* ctx, const ggd_params* prm, const float* means3D, const float* shs,
+                        const float* colors_precomp, const float* scales, const float* rotations,
+                        const float* cov3D_precomp) {
+  if (prm->P == 0) return GGD_OK;
+  if (!means3D) return ggd_fail(ctx, GGD_E_INVALID, "means3D is NULL");
+  if ((shs == nullptr) == (colors_precomp == nullptr))
+    return ggd_fail(ctx, GGD_E_INVALID, "Please provide excatly one of either SHs or precomputed colors!");
+  if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr) ||
+      ((scales == nullptr) != (rotations == nullptr)))
+    return ggd_fail(ctx, GGD_E_INVALID,
+                    "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+  if (shs && (prm->sh_degree + 1) * (prm->sh_degree + 1) > prm->M)
+    return ggd_fail(ctx, GGD_E_INVALID, "shs holds fewer coefficients than sh_degree needs");
+  return GGD_OK;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------
+extern "C" int ggd_forward_geometry(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D,
+                                    const float* shs, const float* colors_precomp, const float* opacities,
+                                    const float* scales, const float* rotations, const float* cov3D_precomp,
+                                    void* geom_buf, int32_t* radii, int64_t* num_rendered) {
+  int rc = check_params(ctx, prm);
+  if (rc != GGD_OK) return rc;
+  rc = check_inputs(ctx, prm, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp);
+  if (rc != GGD_OK) return rc;
+  if (!num_rendered) return ggd_fail(ctx, GGD_E_INVALID, "num_rendered is NULL");
+  *num_rendered = 0;
+  if (prm->P == 0) return GGD_OK;
+  if (!geom_buf || !radii || !opacities) return ggd_fail(ctx, GGD_E_INVALID, "geom_buf / radii / opacities is NULL");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ggd_geom_view gv;
+  ggd_geom_layout(prm->P, &gv);
+  char* gb = static_cast<char*>(geom_buf);
+  ggd_splat* splat = reinterpret_cast<ggd_splat*>(gb + gv.splat);
+  uint32_t* tiles = reinterpret_cast<uint32_t*>(gb + gv.tiles_touched);
+  uint32_t* offsets = reinterpret_cast<uint32_t*>(gb + gv.point_offsets);
+  uint8_t* clamped = reinterpret_cast<uint8_t*>(gb + gv.clamped);
+
+  const size_t scan_tmp = ggd_scan_tmp_bytes(prm->P);
+  rc = ggd_reserve_scratch(ctx, scan_tmp, s);
+  if (rc != GGD_OK) return rc;
+  if (prm->prefiltered) GGD_HIP(hipMemsetAsync(ctx->d_words + 1, 0, sizeof(uint32_t), s));
+  {
+    StageTimer t(ctx, ST_PREPROCESS, s);
+    rc = ggd_launch_preprocess(ctx, s, *prm, means3D, shs, colors_precomp, opacities, scales, rotations,
+                               cov3D_precomp, splat, tiles, shs ? clamped : nullptr, radii, ctx->d_words + 1);
+    if (rc != GGD_OK) return rc;
+  }
+  {
+    StageTimer t(ctx, ST_SCAN, s);
+    rc = ggd_launch_inclusive_scan(ctx, s, tiles, offsets, prm->P, ctx->d_words, ctx->scratch, ctx->scratch_bytes);
+    if (rc != GGD_OK) return rc;
+  }
+  {
+    StageTimer t(ctx, ST_READBACK, s);
+    GGD_HIP(hipMemcpyAsync(ctx->h_words, ctx->d_words, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  }
+  GGD_HIP(hipStreamSynchronize(s));
+  if (prm->prefiltered && ctx->h_words[1] != 0)
+    return ggd_fail(ctx, GGD_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
+  *num_rendered = (int64_t)ctx->h_words[0];
+  return GGD_OK;
+}
+
+extern "C" int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* prm, const void* geom_buf,
+                                  int64_t R, void* binning_buf, void* img_buf, float* out_color) {
+  int rc = check_params(ctx, prm);
+  if (rc != GGD_OK) return rc;
+  if (R < 0) return ggd_fail(ctx, GGD_E_INVALID, "num_rendered < 0");
+  if (!img_buf || !out_color) return ggd_fail(ctx, GGD_E_INVALID, "img_buf / out_color is NULL");
+  if (R > 0 && (!geom_buf || !binning_buf)) return ggd_fail(ctx, GGD_E_INVALID, "geom_buf / binning_buf is NULL");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ggd_geom_view gv; ggd_binning_view bv; ggd_img_view iv;
+  ggd_geom_layout(prm->P, &gv); ggd_binning_layout(R, &bv); ggd_img_layout(prm->width, prm->height, &iv);
+  const char* gb = static_cast<const char*>(geom_buf);
+  char* bb = static_cast<char*>(binning_buf);
+  char* ib = static_cast<char*>(img_buf);
+  const ggd_splat* splat = reinterpret_cast<const ggd_splat*>(gb + gv.splat);
+  const uint32_t* tiles = reinterpret_cast<const uint32_t*>(gb + gv.tiles_touched);
+  const uint32_t* offsets = reinterpret_cast<const uint32_t*>(gb + gv.point_offsets);
+  uint64_t* keys = reinterpret_cast<uint64_t*>(bb + bv.keys);
+  uint32_t* list = reinterpret_cast<uint32_t*>(bb + bv.list);
+  uint64_t* keys_alt = reinterpret_cast<uint64_t*>(bb + bv.keys_alt);
+  uint32_t* list_alt = reinterpret_cast<uint32_t*>(bb + bv.list_alt);
+  uint32_t* ranges = reinterpret_cast<uint32_t*>(ib + iv.ranges);
+  float* final_T = reinterpret_cast<float*>(ib + iv.final_T);
+  uint32_t* n_contrib = reinterpret_cast<uint32_t*>(ib + iv.n_contrib);
+  const int T = ((prm->width + 15) / 16) * ((prm->height + 15) / 16);
+  const int nbits = ggd_sort_bits(prm->width, prm->height);
+
+  if (R > 0) {
+    const size_t sort_tmp = ggd_sort_tmp_bytes(R);
+    rc = ggd_reserve_scratch(ctx, sort_tmp, s);
+    if (rc != GGD_OK) return rc;
+    const bool to_alt = ggd_sort_input_is_alt(nbits) != 0;
+    uint64_t* k0 = to_alt ? keys_alt : keys;
+    uint32_t* v0 = to_alt ? list_alt : list;
+    {
+      StageTimer t(ctx, ST_DUPLICATE, s);
+      rc = ggd_launch_duplicate(ctx, s, *prm, splat, tiles, offsets, k0, v0);
+      if (rc != GGD_OK) return rc;
+    }
+    if (prm->debug) {
+      if (ctx->dbg_cap < (size_t)R) {
+        if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);
+        if (ctx->dbg_vals) (void)hipFree(ctx->dbg_vals);
+        ctx->dbg_keys = ctx->dbg_vals = nullptr; ctx->dbg_cap = 0;
+        GGD_HIP(hipMalloc(&ctx->dbg_keys, (size_t)R * sizeof(uint64_t)));
+        GGD_HIP(hipMalloc(&ctx->dbg_vals, (size_t)R * sizeof(uint32_t)));
+        ctx->dbg_cap = (size_t)R;
+      }
+      GGD_HIP(hipMemcpyAsync(ctx->dbg_keys, k0, (size_t)R * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+      GGD_HIP(hipMemcpyAsync(ctx->dbg_vals, v0, (size_t)R * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    }
+    {
+      StageTimer t(ctx, ST_SORT, s);
+      rc = ggd_launch_sort(ctx, s, keys, list, keys_alt, list_alt, R, nbits, ctx->scratch, ctx->scratch_bytes);
+      if (rc != GGD_OK) return rc;
+    }
+  }
+  {
+    StageTimer t(ctx, ST_RANGES, s);
+    rc = ggd_launch_ranges(ctx, s, keys, R, ranges, T);
+    if (rc != GGD_OK) return rc;
+  }
+  {
+    StageTimer t(ctx, ST_BLEND, s);
+    rc = ggd_launch_blend(ctx, s, *prm, splat, list, ranges, out_color, final_T, n_contrib);
+    if (rc != GGD_OK) return rc;
+  }
+  return GGD_OK;
+}
+
+// ---- backward --------------------------------------------------------------------------------------------------
+extern "C" int ggd_backward(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D,
+                            const float* shs, const float* colors_precomp, const float* scales,
+                            const float* rotations, const float* cov3D_precomp, const int32_t* radii,
+                            const void* geom_buf, const void* binning_buf, const void* img_buf, int64_t R,
+                            const float* dL_dpix, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+                            float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
+                            float* dL_drots) {
+  int rc = check_params(ctx, prm);
+  if (rc != GGD_OK) return rc;
+  rc = check_inputs(ctx, prm, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp);
+  if (rc != GGD_OK) return rc;
+  const int P = prm->P;
+  if (P == 0) return GGD_OK;
+  if (!radii || !geom_buf || !img_buf || !dL_dpix || !dL_dmeans2D || !dL_dcolors || !dL_dopacity ||
+      !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drots || (prm->M > 0 && !dL_dsh) || (R > 0 && !binning_buf))
+    return ggd_fail(ctx, GGD_E_INVALID, "ggd_backward: NULL buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ggd_geom_view gv; ggd_binning_view bv; ggd_img_view iv;
+  ggd_geom_layout(P, &gv); ggd_binning_layout(R, &bv); ggd_img_layout(prm->width, prm->height, &iv);
+  const char* gb = static_cast<const char*>(geom_buf);
+  const char* bb = static_cast<const char*>(binning_buf);
+  const char* ib = static_cast<const char*>(img_buf);
+  const ggd_splat* splat = reinterpret_cast<const ggd_splat*>(gb + gv.splat);
+  const uint8_t* clamped = reinterpret_cast<const uint8_t*>(gb + gv.clamped);
+  const uint32_t* list = reinterpret_cast<const uint32_t*>(bb + bv.list);
+  const uint32_t* ranges = reinterpret_cast<const uint32_t*>(ib + iv.ranges);
+  const float* final_T = reinterpret_cast<const float*>(ib + iv.final_T);
+  const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(ib + iv.n_contrib);
+
+  rc = ggd_reserve_scratch(ctx, ggd_align((size_t)P * 4 * sizeof(float)), s);
+  if (rc != GGD_OK) return rc;
+  float* dL_dconic = static_cast<float*>(ctx->scratch);
+
+  GGD_HIP(hipMemsetAsync(dL_dconic, 0, (size_t)P * 4 * sizeof(float), s));
+  GGD_HIP(hipMemsetAsync(dL_dmeans2D, 0, (size_t)P * 3 * sizeof(float), s));
+  GGD_HIP(hipMemsetAsync(dL_dcolors, 0, (size_t)P * 3 * sizeof(float), s));
+  GGD_HIP(hipMemsetAsync(dL_dopacity, 0, (size_t)P * sizeof(float), s));
+  GGD_HIP(hipMemsetAsync(dL_dmeans3D, 0, (size_t)P * 3 * sizeof(float), s));
+  GGD_HIP(hipMemsetAsync(dL_dcov3D, 0, (size_t)P * 6 * sizeof(float), s));
+  GGD_HIP(hipMemsetAsync(dL_dscales, 0, (size_t)P * 3 * sizeof(float), s));
+  GGD_HIP(hipMemsetAsync(dL_drots, 0, (size_t)P * 4 * sizeof(float), s));
+  if (prm->M > 0 && dL_dsh) GGD_HIP(hipMemsetAsync(dL_dsh, 0, (size_t)P * prm->M * 3 * sizeof(float), s));
+
+  if (R > 0) {
+    StageTimer t(ctx, ST_BLEND_BWD, s);
+    rc = ggd_launch_blend_backward(ctx, s, *prm, splat, list, ranges, final_T, n_contrib, dL_dpix, dL_dmeans2D,
+                                   dL_dconic, dL_dopacity, dL_dcolors);
+    if (rc != GGD_OK) return rc;
+  }
+  {
+    StageTimer t(ctx, ST_PREPROCESS_BWD, s);
+    rc = ggd_launch_preprocess_backward(ctx, s, *prm, means3D, shs, colors_precomp, scales, rotations,
+                                        cov3D_precomp, radii, shs ? clamped : nullptr, dL_dmeans2D, dL_dconic,
+                                        dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots);
+    if (rc != GGD_OK) return rc;
+  }
+  return GGD_OK;
+}
+
+extern "C" int ggd_mark_visible(ggd_ctx* ctx, void* stream, int32_t P, const float* means3D,
+                                const float* viewmatrix, const float* projmatrix, uint8_t* present) {
+  (void)projmatrix;  // the frustum test only needs view-space z (upstream computes p_proj and ignores it)
+  if (!ctx) return GGD_E_INVALID;
+  if (P < 0) return ggd_fail(ctx, GGD_E_INVALID, "P < 0");
+  if (P == 0) return GGD_OK;
+  if (!means3D || !viewmatrix || !present) return ggd_fail(ctx, GGD_E_INVALID, "ggd_mark_visible: NULL pointer");
+  return ggd_launch_mark_visible(ctx, static_cast<hipStream_t>(stream), P, means3D, viewmatrix, present);
+}
+
+extern "C" int ggd_debug_unsorted(ggd_ctx* ctx, void* stream, uint64_t* keys, uint32_t* values, int64_t R) {
+  if (!ctx) return GGD_E_INVALID;
+  if (R < 0 || (size_t)R > ctx->dbg_cap) return ggd_fail(ctx, GGD_E_INVALID, "no debug copy of that size (debug=1?)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (keys && R) GGD_HIP(hipMemcpyAsync(keys, ctx->dbg_keys, (size_t)R * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+  if (values && R) GGD_HIP(hipMemcpyAsync(values, ctx->dbg_vals, (size_t)R * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  return GGD_OK;
+}

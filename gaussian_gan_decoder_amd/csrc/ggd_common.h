@@ -1,0 +1,122 @@
+// ggd_common.h -- shared declarations of the gfx950 rasterizer library (host ctx + device helpers).
+//
+// Arithmetic contract: every translation unit is compiled with -ffp-contract=off, so an fp32 expression written
+// here is evaluated as written (IEEE mul/add/div/sqrt, correctly rounded) unless it says __builtin_fmaf
+// explicitly.  The per-Gaussian stage keeps the operation order of the algorithm's published form so that its
+// integer outputs (radii, tiles_touched, depth bits -> sort keys) are reproducible bit-for-bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "ggd_raster.h"
+
+#define GGD_WAVE 64
+
+// Stage ids for the optional hipEvent profiler (ggd_set_profiling).
+enum {
+  ST_PREPROCESS = 0, ST_SCAN, ST_READBACK, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_BLEND,
+  ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT
+};
+
+struct ggd_ctx {
+  int device = 0;
+  void* scratch = nullptr;      // grow-only device workspace (sort histograms, scan block sums, dL_dconic, ...)
+  size_t scratch_bytes = 0;
+  uint32_t* d_words = nullptr;  // small device control block: [0] total R, [1] prefilter trap flag
+  uint32_t* h_words = nullptr;  // pinned host mirror
+  void* dbg_keys = nullptr;     // debug copy of the unsorted list
+  void* dbg_vals = nullptr;
+  size_t dbg_cap = 0;
+  bool profiling = false;
+  hipEvent_t ev[2 * ST_COUNT] = {};
+  bool ev_used[ST_COUNT] = {};
+  std::string err;
+};
+
+int ggd_fail(ggd_ctx* ctx, int code, const std::string& msg);
+int ggd_reserve_scratch(ggd_ctx* ctx, size_t bytes, hipStream_t stream);
+
+#define GGD_HIP(call)                                                                                      \
+  do {                                                                                                     \
+    hipError_t e_ = (call);                                                                                \
+    if (e_ != hipSuccess)                                                                                  \
+      return ggd_fail(ctx, GGD_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                \
+  } while (0)
+
+struct StageTimer {  // RAII hipEvent pair around one pipeline stage (no-op unless profiling is on)
+  ggd_ctx* c; int st; hipStream_t s;
+  StageTimer(ggd_ctx* ctx, int stage, hipStream_t stream) : c(ctx), st(stage), s(stream) {
+    if (c->profiling) { (void)hipEventRecord(c->ev[2 * st], s); }
+  }
+  ~StageTimer() {
+    if (c->profiling) { (void)hipEventRecord(c->ev[2 * st + 1], s); c->ev_used[st] = true; }
+  }
+};
+
+static inline size_t ggd_align(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// ---- kernels launched by the C API (defined in the .hip files) ------------------------------------------------
+int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const float* means3D,
+                          const float* shs, const float* colors_precomp, const float* opacities,
+                          const float* scales, const float* rotations, const float* cov3D_precomp,
+                          ggd_splat* splat, uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii,
+                          uint32_t* trap_flag);
+int ggd_launch_mark_visible(ggd_ctx* ctx, hipStream_t s, int P, const float* means3D, const float* view,
+                            uint8_t* present);
+// inclusive scan of a uint32 array; total written to *d_total (device)
+int ggd_launch_inclusive_scan(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, uint32_t* out, int64_t n,
+                              uint32_t* d_total, void* tmp, size_t tmp_bytes);
+size_t ggd_scan_tmp_bytes(int64_t n);
+int ggd_launch_duplicate(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
+                         const uint32_t* tiles_touched, const uint32_t* offsets, uint64_t* keys, uint32_t* vals);
+size_t ggd_sort_tmp_bytes(int64_t n);
+// stable LSD radix sort of (key,val) pairs on key bits [0,nbits); result ends in (keys_a, vals_a); the input must
+// have been placed in the buffer ggd_sort_input_is_alt(nbits) says.
+int ggd_sort_input_is_alt(int nbits);
+int ggd_launch_sort(ggd_ctx* ctx, hipStream_t s, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b,
+                    uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes);
+int ggd_launch_ranges(ggd_ctx* ctx, hipStream_t s, const uint64_t* keys, int64_t n, uint32_t* ranges, int T);
+int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
+                     const uint32_t* list, const uint32_t* ranges, float* out_color, float* final_T,
+                     uint32_t* n_contrib);
+int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
+                              const uint32_t* list, const uint32_t* ranges, const float* final_T,
+                              const uint32_t* n_contrib, const float* dL_dpix, float* dL_dmean2D /*[P,3]*/,
+                              float* dL_dconic /*[P,4]*/, float* dL_dopacity, float* dL_dcolors);
+int ggd_launch_preprocess_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const float* means3D,
+                                   const float* shs, const float* colors_precomp, const float* scales,
+                                   const float* rotations, const float* cov3D_precomp, const int32_t* radii,
+                                   const uint8_t* clamped, const float* dL_dmean2D, const float* dL_dconic,
+                                   const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                                   float* dL_dscales, float* dL_drots);
+
+// ---- device helpers -----------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int ggd_tile_rect(float px, float py, int irad, int gx, int gy, int& minx, int& miny,
+                                             int& maxx, int& maxy) {
+  // C-style truncation of (p -/+ r [+15]) / 16, clamped to the tile grid.  float->int saturates on gfx950.
+  const float fr = (float)irad;
+  minx = min(gx, max(0, (int)((px - fr) / 16.0f)));
+  miny = min(gy, max(0, (int)((py - fr) / 16.0f)));
+  maxx = min(gx, max(0, (int)((px + fr + 15.0f) / 16.0f)));
+  maxy = min(gy, max(0, (int)((py + fr + 15.0f) / 16.0f)));
+  return (maxx - minx) * (maxy - miny);
+}
+
+// Sum over the 64 lanes of a wave with DPP row shifts / broadcasts; the total is valid in lane 63.
+// (Hillis-Steele inclusive scan inside each 16-lane row, then row_bcast:15 into rows 1/3 and row_bcast:31 into
+// rows 2/3; lanes without a valid source add the `old` operand = 0.)
+#define GGD_DPP_ADD(v, ctrl, rowmask)                                                                         \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rowmask, 0xf, false))
+__device__ __forceinline__ float ggd_wave_sum_to63(float v) {
+  GGD_DPP_ADD(v, 0x111, 0xf);  // row_shr:1
+  GGD_DPP_ADD(v, 0x112, 0xf);  // row_shr:2
+  GGD_DPP_ADD(v, 0x114, 0xf);  // row_shr:4
+  GGD_DPP_ADD(v, 0x118, 0xf);  // row_shr:8
+  GGD_DPP_ADD(v, 0x142, 0xa);  // row_bcast:15 -> rows 1, 3
+  GGD_DPP_ADD(v, 0x143, 0xc);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+#endif

@@ -1,0 +1,142 @@
+// ggd_preprocess.hip -- stage a4 (per-Gaussian forward) and a12 (mark_visible) for gfx950.
+//
+// Replaces the per-Gaussian half of `_C.rasterize_gaussians` that the reference reaches through
+// gaussian_splatting/gaussian_renderer/__init__.py:167-175 (source not in the reference tree; algorithm restated
+// in SURVEY.md section 9.2).  One lane per Gaussian, 256-lane workgroups; every input array is read exactly once
+// with per-lane vector loads over contiguous addresses (a wave covers 64 consecutive Gaussians = one contiguous
+// 768 B / 1 KiB span per array), and the outputs the blend needs are packed into ONE 48-byte record per Gaussian
+// (ggd_splat) so that the per-tile gather later touches a single 64 B-aligned-ish record instead of four arrays.
+// HBM-bound: 56 B in (degree 0) + 56 B out per visible Gaussian, 56 B in + 8 B out per culled one.
+#include "ggd_math.h"
+
+namespace {
+using namespace ggdm;
+
+__global__ __launch_bounds__(256) void preprocess_kernel(
+    int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered,
+    const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos_p,
+    const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+    const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ cov3D_precomp, ggd_splat* __restrict__ splat, uint32_t* __restrict__ tiles_touched,
+    uint8_t* __restrict__ clamped, int32_t* __restrict__ radii, uint32_t* __restrict__ trap_flag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const Mat16 V = load_mat(view);
+  const Mat16 PV = load_mat(proj);
+
+  const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+  float t[3];
+  t[0] = V.m[0] * p[0] + V.m[4] * p[1] + V.m[8] * p[2] + V.m[12];
+  t[1] = V.m[1] * p[0] + V.m[5] * p[1] + V.m[9] * p[2] + V.m[13];
+  t[2] = V.m[2] * p[0] + V.m[6] * p[1] + V.m[10] * p[2] + V.m[14];
+
+  int irad = 0;
+  uint32_t ntiles = 0;
+  bool visible = false;
+  ggd_splat out;
+  uint32_t clamp_bits = 0;
+
+  if (t[2] > 0.2f) {
+    float h[4];
+    h[0] = PV.m[0] * p[0] + PV.m[4] * p[1] + PV.m[8] * p[2] + PV.m[12];
+    h[1] = PV.m[1] * p[0] + PV.m[5] * p[1] + PV.m[9] * p[2] + PV.m[13];
+    h[3] = PV.m[3] * p[0] + PV.m[7] * p[1] + PV.m[11] * p[2] + PV.m[15];
+    const float pw = 1.0f / (h[3] + 0.0000001f);
+    const float ndcx = h[0] * pw, ndcy = h[1] * pw;
+
+    float c6[6];
+    if (cov3D_precomp) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * (size_t)i + k];
+    } else {
+      const float s3[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+      const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+      cov3d_from_scale_rot(s3, mod, q, c6);
+    }
+    const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+    float abc[3], Tm[2][3], tcl[3];
+    bool clx, cly;
+    ewa_cov2d(t, fx, fy, tanfovx, tanfovy, c6, V, abc, Tm, tcl, clx, cly);
+    const float a = abc[0] + 0.3f, b = abc[1], c = abc[2] + 0.3f;
+    const float det = a * c - b * b;
+    if (det != 0.0f) {
+      const float det_inv = 1.0f / det;
+      const float mid = 0.5f * (a + c);
+      const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+      const float lambda1 = mid + disc, lambda2 = mid - disc;
+      const float my_radius = ceilf(3.0f * sqrtf(fmaxf(lambda1, lambda2)));
+      const float px = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f;
+      const float py = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
+      const int r_i = (int)my_radius;
+      int minx, miny, maxx, maxy;
+      const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+      const int area = ggd_tile_rect(px, py, r_i, gx, gy, minx, miny, maxx, maxy);
+      if (area != 0) {
+        visible = true;
+        irad = r_i;
+        ntiles = (uint32_t)area;
+        float rgb[3];
+        if (colors_precomp) {
+          rgb[0] = colors_precomp[3 * (size_t)i]; rgb[1] = colors_precomp[3 * (size_t)i + 1];
+          rgb[2] = colors_precomp[3 * (size_t)i + 2];
+        } else {
+          const float campos[3] = {campos_p[0], campos_p[1], campos_p[2]};
+          sh_to_rgb(deg, shs + (size_t)i * M * 3, p, campos, rgb, clamp_bits);
+        }
+        out.x = px; out.y = py;
+        out.conA = c * det_inv; out.conB = -b * det_inv; out.conC = a * det_inv;
+        out.opacity = opacities[i];
+        out.r = rgb[0]; out.g = rgb[1]; out.b = rgb[2];
+        out.depth = t[2];
+        out.radius = irad;
+        out.tiles_touched = ntiles;
+      }
+    }
+  } else if (prefiltered) {
+    atomicOr(trap_flag, 1u);  // upstream traps here; we report GGD_E_PREFILTER instead
+  }
+
+  radii[i] = irad;
+  tiles_touched[i] = ntiles;
+  if (clamped) clamped[i] = (uint8_t)clamp_bits;
+  if (visible) {
+    float4* dst = reinterpret_cast<float4*>(splat + i);
+    const float4* src = reinterpret_cast<const float4*>(&out);
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+  }
+}
+
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                           const float* __restrict__ view,
+                                                           uint8_t* __restrict__ present) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const float x = means3D[3 * (size_t)i], y = means3D[3 * (size_t)i + 1], z = means3D[3 * (size_t)i + 2];
+  const float tz = view[2] * x + view[6] * y + view[10] * z + view[14];
+  present[i] = (uint8_t)(tz > 0.2f);
+}
+
+}  // namespace
+
+int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const float* means3D,
+                          const float* shs, const float* colors_precomp, const float* opacities,
+                          const float* scales, const float* rotations, const float* cov3D_precomp,
+                          ggd_splat* splat, uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii,
+                          uint32_t* trap_flag) {
+  if (prm.P == 0) return GGD_OK;
+  const int grid = (prm.P + 255) / 256;
+  hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, s, prm.P, prm.M, prm.sh_degree, prm.width,
+                     prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.viewmatrix,
+                     prm.projmatrix, prm.campos, means3D, shs, colors_precomp, opacities, scales, rotations,
+                     cov3D_precomp, splat, tiles_touched, clamped, radii, trap_flag);
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
+int ggd_launch_mark_visible(ggd_ctx* ctx, hipStream_t s, int P, const float* means3D, const float* view,
+                            uint8_t* present) {
+  if (P == 0) return GGD_OK;
+  hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}

@@ -1,0 +1,239 @@
+// ggd_preprocess_bwd.hip -- stage a11: per-Gaussian backward (conic -> cov2D -> cov3D / view point; screen
+// position through the perspective divide; colour -> SH (+ view direction); cov3D -> scale, quaternion).
+//
+// Replaces computeCov2D-backward + preprocess-backward inside `_C.rasterize_gaussians_backward`, which the
+// reference reaches through autograd from main/train_pano2gaussian_decoder.py:263 (loss.backward()).  Algorithm:
+// SURVEY.md section 9.6.  One lane per Gaussian, fused into ONE streaming pass (upstream runs two kernels and
+// round-trips dL_dcov3D through memory when scales/rotations are given); cov3D is recomputed from scale/rotation
+// instead of being stored by the forward pass (saves 24 B/Gaussian written + read).
+// Conventions kept from the published algorithm because they change values beyond the 1e-5 tolerance otherwise:
+// 1/(det^2 + 1e-7) in the conic inverse, dL_dconic slot 1 = half the true d/dB, and the clamped view-space x,y
+// treated as independent of z.
+#include "ggd_math.h"
+
+namespace {
+using namespace ggdm;
+
+__global__ __launch_bounds__(256) void preprocess_backward_kernel(
+    int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod,
+    const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos_p,
+    const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+    const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+    const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
+    const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic, const float* __restrict__ dL_dcolors,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dscales, float* __restrict__ dL_drots) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  if (radii[i] <= 0) return;  // outputs were zero-filled by the caller
+  const size_t ii = (size_t)i;
+  const Mat16 V = load_mat(view);
+  const Mat16 PV = load_mat(proj);
+  const float p[3] = {means3D[3 * ii], means3D[3 * ii + 1], means3D[3 * ii + 2]};
+
+  float c6[6];
+  float4 q = make_float4(0, 0, 0, 0);
+  float s3[3] = {0, 0, 0};
+  if (cov3D_precomp) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * ii + k];
+  } else {
+    s3[0] = scales[3 * ii]; s3[1] = scales[3 * ii + 1]; s3[2] = scales[3 * ii + 2];
+    q = reinterpret_cast<const float4*>(rotations)[i];
+    cov3d_from_scale_rot(s3, mod, q, c6);
+  }
+
+  float dmean[3];
+  float dc[6] = {0, 0, 0, 0, 0, 0};
+  // (1) conic -> cov2D -> cov3D, view-space point
+  {
+    float t[3];
+    t[0] = V.m[0] * p[0] + V.m[4] * p[1] + V.m[8] * p[2] + V.m[12];
+    t[1] = V.m[1] * p[0] + V.m[5] * p[1] + V.m[9] * p[2] + V.m[13];
+    t[2] = V.m[2] * p[0] + V.m[6] * p[1] + V.m[10] * p[2] + V.m[14];
+    const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+    float abc[3], T[2][3], tc[3];
+    bool clx, cly;
+    ewa_cov2d(t, fx, fy, tanfovx, tanfovy, c6, V, abc, T, tc, clx, cly);
+    const float x_grad_mul = clx ? 0.0f : 1.0f, y_grad_mul = cly ? 0.0f : 1.0f;
+    const float a = abc[0] + 0.3f, b = abc[1], c = abc[2] + 0.3f;
+    const float denom = a * c - b * b;
+    const float denom2inv = 1.0f / (denom * denom + 0.0000001f);
+    const float4 gcon = reinterpret_cast<const float4*>(dL_dconic)[i];
+    const float gA = gcon.x, gB = gcon.y, gC = gcon.z;
+    float dL_da = 0.0f, dL_db = 0.0f, dL_dc = 0.0f;
+    if (denom2inv != 0.0f) {
+      dL_da = denom2inv * (-c * c * gA + 2.0f * b * c * gB + (denom - a * c) * gC);
+      dL_dc = denom2inv * (-a * a * gC + 2.0f * a * b * gB + (denom - a * c) * gA);
+      dL_db = denom2inv * 2.0f * (b * c * gA - (denom + 2.0f * b * b) * gB + a * b * gC);
+      dc[0] = T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc;
+      dc[3] = T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc;
+      dc[5] = T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc;
+      dc[1] = 2.0f * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db +
+              2.0f * T[1][0] * T[1][1] * dL_dc;
+      dc[2] = 2.0f * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db +
+              2.0f * T[1][0] * T[1][2] * dL_dc;
+      dc[4] = 2.0f * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db +
+              2.0f * T[1][1] * T[1][2] * dL_dc;
+    }
+    const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    float dT[2][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float s0 = T[0][0] * S[0][j] + T[0][1] * S[1][j] + T[0][2] * S[2][j];
+      const float s1 = T[1][0] * S[0][j] + T[1][1] * S[1][j] + T[1][2] * S[2][j];
+      dT[0][j] = 2.0f * s0 * dL_da + s1 * dL_db;
+      dT[1][j] = 2.0f * s1 * dL_dc + s0 * dL_db;
+    }
+    // W[r][c] = V.m[4c + r]
+    const float dJ00 = V.m[0] * dT[0][0] + V.m[4] * dT[0][1] + V.m[8] * dT[0][2];
+    const float dJ02 = V.m[2] * dT[0][0] + V.m[6] * dT[0][1] + V.m[10] * dT[0][2];
+    const float dJ11 = V.m[1] * dT[1][0] + V.m[5] * dT[1][1] + V.m[9] * dT[1][2];
+    const float dJ12 = V.m[2] * dT[1][0] + V.m[6] * dT[1][1] + V.m[10] * dT[1][2];
+    const float tz = 1.0f / tc[2], tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dtx = x_grad_mul * -fx * tz2 * dJ02;
+    const float dty = y_grad_mul * -fy * tz2 * dJ12;
+    const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.0f * fx * tc[0]) * tz3 * dJ02 +
+                      (2.0f * fy * tc[1]) * tz3 * dJ12;
+    dmean[0] = V.m[0] * dtx + V.m[1] * dty + V.m[2] * dtz;
+    dmean[1] = V.m[4] * dtx + V.m[5] * dty + V.m[6] * dtz;
+    dmean[2] = V.m[8] * dtx + V.m[9] * dty + V.m[10] * dtz;
+  }
+  // (2) screen position through the perspective divide
+  {
+    const float h0 = PV.m[0] * p[0] + PV.m[4] * p[1] + PV.m[8] * p[2] + PV.m[12];
+    const float h1 = PV.m[1] * p[0] + PV.m[5] * p[1] + PV.m[9] * p[2] + PV.m[13];
+    const float h3 = PV.m[3] * p[0] + PV.m[7] * p[1] + PV.m[11] * p[2] + PV.m[15];
+    const float m_w = 1.0f / (h3 + 0.0000001f);
+    const float mul1 = h0 * m_w * m_w, mul2 = h1 * m_w * m_w;
+    const float g0 = dL_dmean2D[3 * ii], g1 = dL_dmean2D[3 * ii + 1];
+    dmean[0] += (PV.m[0] * m_w - PV.m[3] * mul1) * g0 + (PV.m[1] * m_w - PV.m[3] * mul2) * g1;
+    dmean[1] += (PV.m[4] * m_w - PV.m[7] * mul1) * g0 + (PV.m[5] * m_w - PV.m[7] * mul2) * g1;
+    dmean[2] += (PV.m[8] * m_w - PV.m[11] * mul1) * g0 + (PV.m[9] * m_w - PV.m[11] * mul2) * g1;
+  }
+  // (3) colour -> SH coefficients (+ position through the view direction when deg > 0)
+  if (!colors_precomp) {
+    const float* sh = shs + ii * M * 3;
+    float* dsh = dL_dsh + ii * M * 3;
+    const uint32_t cl = clamped[i];
+    const float v0 = p[0] - campos_p[0], v1 = p[1] - campos_p[1], v2 = p[2] - campos_p[2];
+    const float len = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+    const float x = v0 / len, y = v1 / len, z = v2 / len;
+    float ddir[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float gcol = ((cl >> c) & 1u) ? 0.0f : dL_dcolors[3 * ii + c];
+#define SHK(k) sh[(k) * 3 + c]
+#define DSH(k) dsh[(k) * 3 + c]
+      float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+      DSH(0) = SH_C0 * gcol;
+      if (deg > 0) {
+        DSH(1) = -SH_C1 * y * gcol; DSH(2) = SH_C1 * z * gcol; DSH(3) = -SH_C1 * x * gcol;
+        dx = -SH_C1 * SHK(3); dy = -SH_C1 * SHK(1); dz = SH_C1 * SHK(2);
+        if (deg > 1) {
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          DSH(4) = SH_C2[0] * xy * gcol; DSH(5) = SH_C2[1] * yz * gcol;
+          DSH(6) = SH_C2[2] * (2.0f * zz - xx - yy) * gcol;
+          DSH(7) = SH_C2[3] * xz * gcol; DSH(8) = SH_C2[4] * (xx - yy) * gcol;
+          dx += SH_C2[0] * y * SHK(4) + SH_C2[2] * 2.0f * -x * SHK(6) + SH_C2[3] * z * SHK(7) +
+                SH_C2[4] * 2.0f * x * SHK(8);
+          dy += SH_C2[0] * x * SHK(4) + SH_C2[1] * z * SHK(5) + SH_C2[2] * 2.0f * -y * SHK(6) +
+                SH_C2[4] * 2.0f * -y * SHK(8);
+          dz += SH_C2[1] * y * SHK(5) + SH_C2[2] * 4.0f * z * SHK(6) + SH_C2[3] * x * SHK(7);
+          if (deg > 2) {
+            DSH(9) = SH_C3[0] * y * (3.0f * xx - yy) * gcol;
+            DSH(10) = SH_C3[1] * xy * z * gcol;
+            DSH(11) = SH_C3[2] * y * (4.0f * zz - xx - yy) * gcol;
+            DSH(12) = SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * gcol;
+            DSH(13) = SH_C3[4] * x * (4.0f * zz - xx - yy) * gcol;
+            DSH(14) = SH_C3[5] * z * (xx - yy) * gcol;
+            DSH(15) = SH_C3[6] * x * (xx - 3.0f * yy) * gcol;
+            dx += SH_C3[0] * SHK(9) * 6.0f * xy + SH_C3[1] * SHK(10) * yz + SH_C3[2] * SHK(11) * -2.0f * xy +
+                  SH_C3[3] * SHK(12) * -6.0f * xz + SH_C3[4] * SHK(13) * (4.0f * zz - 3.0f * xx - yy) +
+                  SH_C3[5] * SHK(14) * 2.0f * xz + SH_C3[6] * SHK(15) * 3.0f * (xx - yy);
+            dy += SH_C3[0] * SHK(9) * 3.0f * (xx - yy) + SH_C3[1] * SHK(10) * xz +
+                  SH_C3[2] * SHK(11) * (4.0f * zz - xx - 3.0f * yy) + SH_C3[3] * SHK(12) * -6.0f * yz +
+                  SH_C3[4] * SHK(13) * -2.0f * xy + SH_C3[5] * SHK(14) * -2.0f * yz +
+                  SH_C3[6] * SHK(15) * -6.0f * xy;
+            dz += SH_C3[1] * SHK(10) * xy + SH_C3[2] * SHK(11) * 8.0f * yz +
+                  SH_C3[3] * SHK(12) * 3.0f * (2.0f * zz - xx - yy) + SH_C3[4] * SHK(13) * 8.0f * xz +
+                  SH_C3[5] * SHK(14) * (xx - yy);
+          }
+        }
+      }
+#undef SHK
+#undef DSH
+      ddir[0] += dx * gcol; ddir[1] += dy * gcol; ddir[2] += dz * gcol;
+    }
+    if (deg > 0) {
+      const float sum2 = v0 * v0 + v1 * v1 + v2 * v2;
+      const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+      dmean[0] += ((sum2 - v0 * v0) * ddir[0] - v1 * v0 * ddir[1] - v2 * v0 * ddir[2]) * invsum32;
+      dmean[1] += (-v0 * v1 * ddir[0] + (sum2 - v1 * v1) * ddir[1] - v2 * v1 * ddir[2]) * invsum32;
+      dmean[2] += (-v0 * v2 * ddir[0] - v1 * v2 * ddir[1] + (sum2 - v2 * v2) * ddir[2]) * invsum32;
+    }
+  }
+  dL_dmeans3D[3 * ii] = dmean[0]; dL_dmeans3D[3 * ii + 1] = dmean[1]; dL_dmeans3D[3 * ii + 2] = dmean[2];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) dL_dcov3D[6 * ii + k] = dc[k];
+
+  // (4) cov3D -> scale, quaternion
+  if (!cov3D_precomp) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    float R[3][3];
+    R[0][0] = 1.0f - 2.0f * (y * y + z * z); R[0][1] = 2.0f * (x * y - r * z); R[0][2] = 2.0f * (x * z + r * y);
+    R[1][0] = 2.0f * (x * y + r * z); R[1][1] = 1.0f - 2.0f * (x * x + z * z); R[1][2] = 2.0f * (y * z - r * x);
+    R[2][0] = 2.0f * (x * z - r * y); R[2][1] = 2.0f * (y * z + r * x); R[2][2] = 1.0f - 2.0f * (x * x + y * y);
+    const float s[3] = {mod * s3[0], mod * s3[1], mod * s3[2]};
+    float Mm[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Mm[k][j] = s[k] * R[j][k];
+    const float Gs[3][3] = {{dc[0], 0.5f * dc[1], 0.5f * dc[2]},
+                            {0.5f * dc[1], dc[3], 0.5f * dc[4]},
+                            {0.5f * dc[2], 0.5f * dc[4], dc[5]}};
+    float dM[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        dM[k][j] = 2.0f * (Mm[k][0] * Gs[0][j] + Mm[k][1] * Gs[1][j] + Mm[k][2] * Gs[2][j]);
+    float Q[3][3];
+    float dscale[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      dscale[k] = mod * (R[0][k] * dM[k][0] + R[1][k] * dM[k][1] + R[2][k] * dM[k][2]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Q[j][k] = dM[k][j] * s[k];
+    }
+    dL_dscales[3 * ii] = dscale[0]; dL_dscales[3 * ii + 1] = dscale[1]; dL_dscales[3 * ii + 2] = dscale[2];
+    float4 dq;
+    dq.x = 2.0f * (-z * Q[0][1] + y * Q[0][2] + z * Q[1][0] - x * Q[1][2] - y * Q[2][0] + x * Q[2][1]);
+    dq.y = 2.0f * (y * Q[0][1] + z * Q[0][2] + y * Q[1][0] - 2.0f * x * Q[1][1] - r * Q[1][2] + z * Q[2][0] +
+                   r * Q[2][1] - 2.0f * x * Q[2][2]);
+    dq.z = 2.0f * (-2.0f * y * Q[0][0] + x * Q[0][1] + r * Q[0][2] + x * Q[1][0] + z * Q[1][2] - r * Q[2][0] +
+                   z * Q[2][1] - 2.0f * y * Q[2][2]);
+    dq.w = 2.0f * (-2.0f * z * Q[0][0] - r * Q[0][1] + x * Q[0][2] + r * Q[1][0] - 2.0f * z * Q[1][1] +
+                   y * Q[1][2] + x * Q[2][0] + y * Q[2][1]);
+    reinterpret_cast<float4*>(dL_drots)[i] = dq;
+  }
+}
+
+}  // namespace
+
+int ggd_launch_preprocess_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const float* means3D,
+                                   const float* shs, const float* colors_precomp, const float* scales,
+                                   const float* rotations, const float* cov3D_precomp, const int32_t* radii,
+                                   const uint8_t* clamped, const float* dL_dmean2D, const float* dL_dconic,
+                                   const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                                   float* dL_dscales, float* dL_drots) {
+  if (prm.P == 0) return GGD_OK;
+  hipLaunchKernelGGL(preprocess_backward_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, s, prm.P, prm.M,
+                     prm.sh_degree, prm.width, prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier,
+                     prm.viewmatrix, prm.projmatrix, prm.campos, means3D, shs, colors_precomp, scales, rotations,
+                     cov3D_precomp, radii, clamped, dL_dmean2D, dL_dconic, dL_dcolors, dL_dmeans3D, dL_dcov3D,
+                     dL_dsh, dL_dscales, dL_drots);
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}

@@ -1,0 +1,250 @@
+"""PyTorch-facing rasterizer API: the drop-in for the reference's `diff_gaussian_rasterization` module.
+
+Mirrors (names, argument meaning, error behaviour) what the reference imports and calls at
+gaussian_splatting/gaussian_renderer/__init__.py:14,38-53,87-95 (render) and :124-139,167-175 (render_simple):
+
+    GaussianRasterizationSettings   NamedTuple of the per-frame parameters
+    GaussianRasterizer              nn.Module: .forward(means3D, means2D, opacities, shs=None, colors_precomp=None,
+                                    scales=None, rotations=None, cov3D_precomp=None) -> (color[3,H,W], radii[P]);
+                                    .markVisible(positions) -> bool[P]
+    rasterize_gaussians             functional form, positional arguments as upstream
+    _RasterizeGaussians             the autograd.Function; backward returns gradients in INPUT order
+                                    (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds, None)
+
+and the three native entry points of upstream's `_C`, here thin wrappers over the C ABI
+(include/ggd_raster.h) that pass raw device pointers and the current HIP stream:
+
+    rasterize_gaussians_native / rasterize_gaussians_backward_native / mark_visible
+
+All compute happens in libggd_raster.so (hand-written gfx950 kernels).  Tensors must be CUDA(HIP) fp32; there
+is no CPU path -- a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _capi
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.device != device:
+        raise ValueError(f"{name} is on {t.device}, expected {device} (all rasterizer inputs must share a device)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if (t is None or t.numel() == 0) else C.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _params(rs: GaussianRasterizationSettings, P: int, M: int, device, keep: list) -> _capi.Params:
+    view = _f32c(rs.viewmatrix, "viewmatrix", device)
+    proj = _f32c(rs.projmatrix, "projmatrix", device)
+    campos = _f32c(rs.campos, "campos", device)
+    bg = _f32c(rs.bg, "bg", device)
+    if view.numel() != 16 or proj.numel() != 16 or campos.numel() != 3 or bg.numel() != 3:
+        raise ValueError("viewmatrix/projmatrix must have 16 elements, campos/bg 3")
+    keep += [view, proj, campos, bg]
+    return _capi.Params(P, M, int(rs.sh_degree), int(rs.image_width), int(rs.image_height), float(rs.tanfovx),
+                        float(rs.tanfovy), float(rs.scale_modifier), int(bool(rs.prefiltered)),
+                        int(bool(rs.debug)), view.data_ptr(), proj.data_ptr(), campos.data_ptr(), bg.data_ptr())
+
+
+def _require_cuda(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("gaussian_gan_decoder_amd rasterizer needs HIP device tensors (got a CPU tensor); "
+                           "there is no CPU fallback")
+
+
+def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
+                               cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
+                               sh, degree, campos, prefiltered, debug):
+    """== upstream `_C.rasterize_gaussians(...)`: returns
+    (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer)."""
+    _require_cuda(means3D)
+    dev = means3D.device
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise ValueError("means3D must have dimensions (num_points, 3)")
+    P = means3D.size(0)
+    means3D = _f32c(means3D, "means3D", dev)
+    opacities = _f32c(opacities, "opacities", dev)
+    have = lambda t: t is not None and t.numel() > 0
+    sh_c = _f32c(sh, "sh", dev) if have(sh) else None
+    col_c = _f32c(colors_precomp, "colors_precomp", dev) if have(colors_precomp) else None
+    sc_c = _f32c(scales, "scales", dev) if have(scales) else None
+    rot_c = _f32c(rotations, "rotations", dev) if have(rotations) else None
+    cov_c = _f32c(cov3D_precomp, "cov3D_precomp", dev) if have(cov3D_precomp) else None
+    M = 0
+    if sh_c is not None:
+        if sh_c.dim() != 3 or sh_c.size(0) != P or sh_c.size(2) != 3:
+            raise ValueError("sh must have dimensions (num_points, num_coeffs, 3)")
+        M = sh_c.size(1)
+    rs = GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier,
+                                       viewmatrix, projmatrix, degree, campos, prefiltered, debug)
+    keep: list = []
+    prm = _params(rs, P, M, dev, keep)
+    ctx = _capi.context_for(dev)
+    lib = ctx.lib
+    H, W = int(image_height), int(image_width)
+    u8 = dict(dtype=torch.uint8, device=dev)
+    color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    geom = torch.empty((lib.ggd_geom_bytes(P),), **u8)
+    img = torch.empty((lib.ggd_img_bytes(W, H),), **u8)
+    R = C.c_int64(0)
+    stream = _stream(dev)
+    with torch.cuda.device(dev):
+        ctx.check(lib.ggd_forward_geometry(ctx.handle, stream, C.byref(prm), _ptr(means3D), _ptr(sh_c), _ptr(col_c),
+                                           _ptr(opacities), _ptr(sc_c), _ptr(rot_c), _ptr(cov_c), _ptr(geom),
+                                           _ptr(radii), C.byref(R)))
+        binning = torch.empty((lib.ggd_binning_bytes(R.value),), **u8)
+        ctx.check(lib.ggd_forward_render(ctx.handle, stream, C.byref(prm), _ptr(geom), R.value, _ptr(binning),
+                                         _ptr(img), _ptr(color)))
+    return int(R.value), color, radii, geom, binning, img
+
+
+def rasterize_gaussians_backward_native(bg, means3D, radii, colors_precomp, scales, rotations, scale_modifier,
+                                        cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, dL_dout_color, sh,
+                                        degree, campos, geomBuffer, R, binningBuffer, imgBuffer, debug):
+    """== upstream `_C.rasterize_gaussians_backward(...)`: returns
+    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    _require_cuda(means3D)
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = int(dL_dout_color.size(-2)), int(dL_dout_color.size(-1))
+    means3D = _f32c(means3D, "means3D", dev)
+    have = lambda t: t is not None and t.numel() > 0
+    sh_c = _f32c(sh, "sh", dev) if have(sh) else None
+    col_c = _f32c(colors_precomp, "colors_precomp", dev) if have(colors_precomp) else None
+    sc_c = _f32c(scales, "scales", dev) if have(scales) else None
+    rot_c = _f32c(rotations, "rotations", dev) if have(rotations) else None
+    cov_c = _f32c(cov3D_precomp, "cov3D_precomp", dev) if have(cov3D_precomp) else None
+    g = _f32c(dL_dout_color, "dL_dout_color", dev)
+    M = sh_c.size(1) if sh_c is not None else 0
+    rs = GaussianRasterizationSettings(H, W, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix, degree,
+                                       campos, False, debug)
+    keep: list = []
+    prm = _params(rs, P, M, dev, keep)
+    ctx = _capi.context_for(dev)
+    lib = ctx.lib
+    f32 = dict(dtype=torch.float32, device=dev)
+    dL_dmeans3D = torch.empty((P, 3), **f32)
+    dL_dmeans2D = torch.empty((P, 3), **f32)
+    dL_dcolors = torch.empty((P, 3), **f32)
+    dL_dopacity = torch.empty((P, 1), **f32)
+    dL_dcov3D = torch.empty((P, 6), **f32)
+    dL_dsh = torch.empty((P, M, 3), **f32)
+    dL_dscales = torch.empty((P, 3), **f32)
+    dL_drotations = torch.empty((P, 4), **f32)
+    if P > 0:
+        with torch.cuda.device(dev):
+            ctx.check(lib.ggd_backward(ctx.handle, _stream(dev), C.byref(prm), _ptr(means3D), _ptr(sh_c), _ptr(col_c),
+                                       _ptr(sc_c), _ptr(rot_c), _ptr(cov_c), _ptr(radii), _ptr(geomBuffer),
+                                       _ptr(binningBuffer), _ptr(imgBuffer), int(R), _ptr(g), _ptr(dL_dmeans2D),
+                                       _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
+                                       _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations)))
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(positions, viewmatrix, projmatrix):
+    """== upstream `_C.mark_visible`: bool[P], True where the point passes the z > 0.2 frustum test."""
+    _require_cuda(positions)
+    dev = positions.device
+    pos = _f32c(positions, "positions", dev)
+    view = _f32c(viewmatrix, "viewmatrix", dev)
+    proj = _f32c(projmatrix, "projmatrix", dev)
+    P = pos.size(0)
+    out = torch.empty((P,), dtype=torch.uint8, device=dev)
+    ctx = _capi.context_for(dev)
+    with torch.cuda.device(dev):
+        ctx.check(ctx.lib.ggd_mark_visible(ctx.handle, _stream(dev), P, _ptr(pos), _ptr(view), _ptr(proj), _ptr(out)))
+    return out.bool()
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        num_rendered, color, radii, geom, binning, img = rasterize_gaussians_native(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
+            rs.campos, rs.prefiltered, rs.debug)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning,
+                              img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = rasterize_gaussians_backward_native(
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geom,
+            ctx.num_rendered, binning, img, rs.debug)
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
+                grad_rotations, grad_cov3Ds_precomp, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            return mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, rs)

@@ -1,0 +1,94 @@
+"""Shared helpers for the parity tests: build identical inputs for the oracle (numpy) and the HIP path (torch)."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from gaussian_gan_decoder_amd.synthetic import make_scene, make_dL_dpix
+
+
+def scene_inputs(P, size, kind="cube", seed=0, sh_degree=0, use_colors=False, use_cov=False, lsm=-6.0,
+                 fov_deg=12.0, width=None, height=None, scale_modifier=1.0, h=math.pi / 2, v=math.pi / 2):
+    """Returns a dict of CPU torch tensors / scalars describing one rasterizer call."""
+    sc = make_scene(P, size, kind, seed=seed, log_scale_mean=lsm, fov_deg=fov_deg, h=h, v=v)
+    cam = sc.cam
+    g = torch.Generator().manual_seed(seed + 1000)
+    M = (sh_degree + 1) ** 2
+    shs = torch.cat([sc.features_dc, 0.3 * torch.randn(P, M - 1, 3, generator=g)], dim=1) if M > 1 else sc.features_dc
+    W = width or size
+    H = height or size
+    # proper camera centre (inverse of the view matrix) when SH degree > 0 so that `dir` is meaningful
+    campos = torch.inverse(cam.world_view_transform)[3, :3].contiguous() if sh_degree > 0 else cam.camera_center
+    d = dict(P=P, W=W, H=H, sh_degree=sh_degree, scale_modifier=scale_modifier,
+             tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+             means3D=sc.xyz, opacities=sc.opacities, viewmatrix=cam.world_view_transform.contiguous(),
+             projmatrix=cam.full_proj_transform.contiguous(), campos=campos, bg=sc.bg,
+             shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None)
+    if use_colors:
+        d["colors_precomp"] = torch.rand(P, 3, generator=g)
+    else:
+        d["shs"] = shs.contiguous()
+    if use_cov:
+        from gaussian_gan_decoder_amd.gaussian_model import build_covariance_from_scaling_rotation
+        d["cov3D_precomp"] = build_covariance_from_scaling_rotation(sc.scales, scale_modifier, sc.rotations).contiguous()
+    else:
+        d["scales"] = sc.scales.contiguous()
+        d["rotations"] = sc.rotations.contiguous()
+    return d
+
+
+def run_oracle(d, dtype=np.float32, stop_after=None):
+    from oracle import ggd_oracle as O
+    np_ = lambda t: None if t is None else t.numpy()
+    return O.forward(means3D=np_(d["means3D"]), opacities=np_(d["opacities"]), shs=np_(d["shs"]),
+                     colors_precomp=np_(d["colors_precomp"]), scales=np_(d["scales"]), rotations=np_(d["rotations"]),
+                     cov3D_precomp=np_(d["cov3D_precomp"]), viewmatrix=np_(d["viewmatrix"]),
+                     projmatrix=np_(d["projmatrix"]), campos=np_(d["campos"]), bg=np_(d["bg"]), W=d["W"], H=d["H"],
+                     tanfovx=d["tanfovx"], tanfovy=d["tanfovy"], sh_degree=d["sh_degree"],
+                     scale_modifier=d["scale_modifier"], dtype=dtype, stop_after=stop_after)
+
+
+def run_native(d, device="cuda:0", debug=True):
+    """Forward through the C ABI (via the _C-style wrapper); returns dict with torch outputs + decoded buffers."""
+    from gaussian_gan_decoder_amd import rasterizer as R, _capi
+    dev = torch.device(device)
+    t = lambda x: torch.empty(0, device=dev) if x is None else x.to(dev)
+    num_rendered, color, radii, geom, binning, img = R.rasterize_gaussians_native(
+        t(d["bg"]), t(d["means3D"]), t(d["colors_precomp"]), t(d["opacities"]), t(d["scales"]), t(d["rotations"]),
+        d["scale_modifier"], t(d["cov3D_precomp"]), t(d["viewmatrix"]), t(d["projmatrix"]), d["tanfovx"],
+        d["tanfovy"], d["H"], d["W"], t(d["shs"]), d["sh_degree"], t(d["campos"]), False, debug)
+    out = dict(num_rendered=num_rendered, color=color, radii=radii, geom=geom, binning=binning, img=img)
+    out.update(decode_buffers(d["P"], d["W"], d["H"], num_rendered, geom, binning, img))
+    if debug and num_rendered > 0:
+        ctx = _capi.context_for(dev)
+        ku = torch.empty(num_rendered, dtype=torch.int64, device=dev)
+        vu = torch.empty(num_rendered, dtype=torch.int32, device=dev)
+        import ctypes as C
+        ctx.check(ctx.lib.ggd_debug_unsorted(ctx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
+                                             C.c_void_p(ku.data_ptr()), C.c_void_p(vu.data_ptr()), num_rendered))
+        torch.cuda.synchronize(dev)
+        out["keys_unsorted"] = ku.cpu().numpy().view(np.uint64)
+        out["list_unsorted"] = vu.cpu().numpy().view(np.uint32)
+    return out
+
+
+def decode_buffers(P, W, H, R, geom, binning, img):
+    from gaussian_gan_decoder_amd import _capi
+    gv, bv, iv = _capi.geom_view(P), _capi.binning_view(R), _capi.img_view(W, H)
+    g = geom.cpu().numpy(); b = binning.cpu().numpy(); im = img.cpu().numpy()
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    splat = g[gv.splat:gv.splat + 48 * P].view(np.float32).reshape(P, 12)
+    out = dict(
+        xy=splat[:, 0:2], conic_opacity=np.stack([splat[:, 2], splat[:, 3], splat[:, 4], splat[:, 5]], 1),
+        rgb=splat[:, 6:9], depths=splat[:, 9], splat_radius=splat[:, 10].view(np.int32),
+        splat_tiles=splat[:, 11].view(np.uint32),
+        tiles_touched=g[gv.tiles_touched:gv.tiles_touched + 4 * P].view(np.uint32),
+        point_offsets=g[gv.point_offsets:gv.point_offsets + 4 * P].view(np.uint32),
+        clamped=g[gv.clamped:gv.clamped + P],
+        keys=b[bv.keys:bv.keys + 8 * R].view(np.uint64), point_list=b[bv.list:bv.list + 4 * R].view(np.uint32),
+        ranges=im[iv.ranges:iv.ranges + 8 * T].view(np.uint32).reshape(T, 2),
+        final_T=im[iv.final_T:iv.final_T + 4 * W * H].view(np.float32).reshape(H, W),
+        n_contrib=im[iv.n_contrib:iv.n_contrib + 4 * W * H].view(np.uint32).reshape(H, W))
+    return out
