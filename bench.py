@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native Gaussian-splatting raster path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE forward raster (preprocess -> scan -> read back R -> duplicateWithKeys -> radix sort -> tile
+ranges -> blend) of ONE synthetic frame whose inputs already sit in HBM; the workload is BASELINE.json's metric
+configuration: 1 M synthetic Gaussians ("cube" scene of SURVEY.md 8d, seed 0), 1024x1024, SH degree 0, fp32.
+Multi-GPU: the raster of one frame does not shard (global depth sort + per-tile lists), the path shards over
+SCENES: every rank renders its own frames with no data-path collective (weak scaling); value = frames of all
+ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line (contract in the task statement) including
+  "roofline"     -- for the dominant kernel of the step (largest hipEvent stage time): algorithmic bytes per launch
+                    (SURVEY.md 8d per-unit figures, restated in DESIGN.md) / its measured average duration, vs 8 TB/s
+  "cpu_baseline" -- the CPU oracle (oracle/, single thread, "port") timed on this host on the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # name: (P, image size, scene kind)
+    "1M_1024_cube": (1_000_000, 1024, "cube"),
+    "1M_1024_shell": (1_000_000, 1024, "shell"),
+    "100k_512_cube": (100_000, 512, "cube"),
+    "100k_1024_cube": (100_000, 1024, "cube"),
+    "1M_512_cube": (1_000_000, 512, "cube"),
+    "500k_512_cube": (500_000, 512, "cube"),
+}
+
+
+def sort_passes(W, H):
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    msb = max(1, T.bit_length())  # smallest k with T >> k == 0
+    return (32 + msb + 7) // 8
+
+
+def algorithmic_bytes(stage: str, P: int, R: int, W: int, H: int, M: int = 1) -> float:
+    """Per-launch algorithmic bytes of each pipeline stage (the terms of B_fwd / B_bwd)."""
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    return {
+        "preprocess": P * ((44 + 12 * M) + 75),
+        "scan": 8 * P,
+        "duplicate": 20 * P + 12 * R,
+        "sort": 2 * 12 * R * sort_passes(W, H),
+        "ranges": 8 * R + 8 * T,
+        "blend": 40 * R + 20 * W * H,
+        "blend_bwd": 40 * R + 12 * R + 28 * W * H,
+        "preprocess_bwd": P * (56 + 75) + P * (12 + 8 + 24 + 12 * M + 4 + 12 + 16),
+    }[stage]
+
+
+def cpu_baseline(P, S, kind, budget_s=25.0):
+    """Time the CPU oracle (C restatement, one thread) on the SAME workload; if the full frame does not fit the
+    budget, a centred crop of the image is rendered and the time is scaled by the pixel ratio (stated in `sample`)."""
+    from gaussian_gan_decoder_amd.synthetic import make_scene
+    from oracle import ggd_oracle as O
+    sc = make_scene(P, S, kind, seed=0)
+    cam = sc.cam
+    kw = dict(means3D=sc.xyz.numpy(), opacities=sc.opacities.numpy(), shs=sc.features_dc.numpy(),
+              scales=sc.scales.numpy(), rotations=sc.rotations.numpy(), viewmatrix=cam.world_view_transform.numpy(),
+              projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(), bg=sc.bg.numpy(),
+              W=S, H=S, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5))
+    O.lib()
+    t0 = time.perf_counter()
+    O.forward(**kw)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"1 full frame of the same workload ({P} Gaussians, {S}x{S}) through oracle/libggd_oracle.so "
+                      f"(gcc -O2, single thread): {dt:.2f} s",
+            "host_cores": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="1M_1024_cube", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backward", action="store_true", help="also time forward+backward (reported under 'extra')")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 "
+                             f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from gaussian_gan_decoder_amd import _capi, rasterizer as R
+    from gaussian_gan_decoder_amd.synthetic import make_scene, make_dL_dpix
+
+    P, S, kind = WORKLOADS[args.workload]
+    sc = make_scene(P, S, kind, seed=0).to(dev)  # identical scene on every rank (weak scaling: 1 frame/step/rank)
+    cam = sc.cam
+    empty = torch.empty(0, device=dev)
+    scales, rots, opac, shs = sc.scales.contiguous(), sc.rotations.contiguous(), sc.opacities.contiguous(), \
+        sc.features_dc.contiguous()
+    tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    fargs = (sc.bg, sc.xyz, empty, opac, scales, rots, 1.0, empty, cam.world_view_transform,
+             cam.full_proj_transform, tanx, tany, S, S, shs, 0, cam.camera_center, False, False)
+
+    def step():
+        return R.rasterize_gaussians_native(*fargs)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    num_rendered = out[0]
+
+    # ---- per-stage device times (hipEvent pairs on the launch stream), measured live over a second timed region
+    ctx = _capi.context_for(dev)
+    ctx.set_profiling(True)
+    nprof = max(10, min(50, args.steps))
+    acc: dict = {}
+    for _ in range(nprof):
+        step()
+        for k, v in ctx.stage_times().items():
+            acc[k] = acc.get(k, 0.0) + v
+    stage_ms = {k: v / nprof for k, v in acc.items()}
+    extra = {}
+    if args.backward:
+        g = make_dL_dpix(S).to(dev)
+        out = step()
+        bargs = (sc.bg, sc.xyz, out[2], empty, scales, rots, 1.0, empty, cam.world_view_transform,
+                 cam.full_proj_transform, tanx, tany, g, shs, 0, cam.camera_center, out[3], out[0], out[4], out[5],
+                 False)
+        bacc: dict = {}
+        for _ in range(5):
+            R.rasterize_gaussians_backward_native(*bargs)
+        torch.cuda.synchronize(dev)
+        tb = time.perf_counter()
+        for _ in range(nprof):
+            R.rasterize_gaussians_backward_native(*bargs)
+            for k in ("blend_bwd", "preprocess_bwd"):
+                bacc[k] = bacc.get(k, 0.0) + ctx.stage_times()[k]
+        torch.cuda.synchronize(dev)
+        extra["backward_ms"] = (time.perf_counter() - tb) / nprof * 1e3
+        for k, v in bacc.items():
+            stage_ms[k] = v / nprof
+    ctx.set_profiling(False)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    fwd_stages = ("preprocess", "scan", "duplicate", "sort", "ranges", "blend")
+    dom = max(fwd_stages, key=lambda k: stage_ms.get(k, 0.0))
+    dom_bytes = algorithmic_bytes(dom, P, num_rendered, S, S)
+    dom_s = stage_ms[dom] * 1e-3
+    achieved = dom_bytes / dom_s / 1e9
+    whole = sum(algorithmic_bytes(k, P, num_rendered, S, S) for k in fwd_stages)
+    ms_per_step = elapsed / args.steps * 1e3
+    result = {
+        "metric": "forward raster frames/s, 1M Gaussians @ 1024x1024" if args.workload == "1M_1024_cube"
+        else f"forward raster frames/s ({args.workload})",
+        "value": world * args.steps / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{P} synthetic Gaussians ('{kind}' scene, seed 0, SH degree 0), {S}x{S}, forward "
+                               "raster fp32, inputs resident in HBM", "num_rendered": num_rendered,
+                   "tiles": ((S + 15) // 16) ** 2, "parallelism": f"scene-parallel x{world} (no collective)"},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": stage_ms[dom]},
+        "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+        "whole_frame": {"algorithmic_bytes": whole, "GBps": whole / (ms_per_step * 1e-3) / 1e9,
+                        "frac_of_hbm_peak": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+    if extra:
+        result["extra"] = extra
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(P, S, kind)
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

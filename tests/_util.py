@@ -92,3 +92,18 @@ def decode_buffers(P, W, H, R, geom, binning, img):
         final_T=im[iv.final_T:iv.final_T + 4 * W * H].view(np.float32).reshape(H, W),
         n_contrib=im[iv.n_contrib:iv.n_contrib + 4 * W * H].view(np.uint32).reshape(H, W))
     return out
+
+
+def run_native_backward(d, n, dL_dpix, device="cuda:0"):
+    from gaussian_gan_decoder_amd import rasterizer as R
+    dev = torch.device(device)
+    t = lambda x: torch.empty(0, device=dev) if x is None else x.to(dev)
+    outs = R.rasterize_gaussians_backward_native(
+        t(d["bg"]), t(d["means3D"]), n["radii"], t(d["colors_precomp"]), t(d["scales"]), t(d["rotations"]),
+        d["scale_modifier"], t(d["cov3D_precomp"]), t(d["viewmatrix"]), t(d["projmatrix"]), d["tanfovx"],
+        d["tanfovy"], dL_dpix.to(dev), t(d["shs"]), d["sh_degree"], t(d["campos"]), n["geom"], n["num_rendered"],
+        n["binning"], n["img"], False)
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+             "dL_drots")
+    torch.cuda.synchronize(dev)
+    return {k: v.cpu().numpy() for k, v in zip(names, outs)}
