@@ -112,3 +112,12 @@ void ggo_mark_visible(int P, const float* means3D, const float* view, uint8_t* p
     present[i] = (uint8_t)(t[2] > 0.2f);
   }
 }
+
+/* ---- unit-test entry points (let tests/golden pin the pieces that DO have an in-tree Python twin) ----------- */
+void ggo_test_sh_to_rgb(int deg, const float* sh /*[M][3]*/, const float* p, const float* campos, float* rgb,
+                        uint8_t* clamped) {
+  sh_to_rgb_f32(deg, sh, p, campos, rgb, clamped);
+}
+void ggo_test_cov3d(const float* scale3, float mod, const float* quat4, float* cov6) {
+  cov3d_from_scale_rot_f32(scale3, mod, quat4, cov6);
+}

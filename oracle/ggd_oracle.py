@@ -81,7 +81,7 @@ def forward(*, means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tan
     assert ((scales is None) and (rotations is None)) != (cov3D_precomp is None), "exactly one of scale+rot / cov3D"
     opacities = _c(opacities, dt, (-1,))
     shs = _c(shs, dt)
-    M = 0 if shs is None else shs.reshape(P, -1, 3).shape[1]
+    M = 0 if shs is None else (shs.shape[1] if shs.ndim == 3 else shs.reshape(max(P, 1), -1, 3).shape[1])
     if shs is not None:
         shs = shs.reshape(P, M, 3)
         assert (sh_degree + 1) ** 2 <= M
@@ -175,3 +175,20 @@ def mark_visible(means3D, viewmatrix):
     out = np.zeros(m.shape[0], np.uint8)
     L.ggo_mark_visible(m.shape[0], _p(m), _p(v), _p(out))
     return out.astype(bool)
+
+
+def sh_to_rgb(deg, sh, p, campos):
+    """Oracle SH evaluation of ONE Gaussian: sh [M,3], p [3], campos [3] -> (rgb[3], clamped[3])."""
+    L = lib()
+    sh = _c(sh, np.float32); p = _c(p, np.float32, (3,)); cp = _c(campos, np.float32, (3,))
+    rgb = np.zeros(3, np.float32); cl = np.zeros(3, np.uint8)
+    L.ggo_test_sh_to_rgb(int(deg), _p(sh), _p(p), _p(cp), _p(rgb), _p(cl))
+    return rgb, cl
+
+
+def cov3d(scale, mod, quat):
+    L = lib()
+    s = _c(scale, np.float32, (3,)); q = _c(quat, np.float32, (4,))
+    out = np.zeros(6, np.float32)
+    L.ggo_test_cov3d(_p(s), C.c_float(mod), _p(q), _p(out))
+    return out

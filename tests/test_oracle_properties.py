@@ -1,0 +1,115 @@
+"""CPU tests of the oracle itself (nothing in the reference vouches for it):
+finite-difference validation of every gradient on the fp64 twin, and structural properties of the integer stages."""
+import math
+
+import numpy as np
+import pytest
+
+from _util import scene_inputs, run_oracle
+from oracle import ggd_oracle as O
+from gaussian_gan_decoder_amd.synthetic import make_dL_dpix
+
+
+def _fd_check(d, names, trials=8, seed=0):
+    rng = np.random.default_rng(seed)
+    g = make_dL_dpix(max(d["W"], d["H"]))[:, :d["H"], :d["W"]].double().numpy()
+    f = run_oracle(d, dtype=np.float64)
+    b = O.backward(f, g)
+    loss = lambda ff: float((ff["color"] * g).sum())
+    vis = np.nonzero(f["radii"] > 0)[0]
+    assert len(vis) > 10
+    P = d["P"]
+    import torch
+
+    def central(inp, base, i, j, eps):
+        vals = []
+        for sgn in (+1, -1):
+            pert = base.copy(); pert[i, j] += sgn * eps
+            d2 = dict(d); d2[inp] = torch.from_numpy(pert.reshape(tuple(d[inp].shape)))
+            vals.append(loss(run_oracle(d2, dtype=np.float64)))
+        return (vals[0] - vals[1]) / (2 * eps)
+
+    for inp, gname in names.items():
+        base = d[inp].double().numpy().reshape(P, -1)
+        checked = 0
+        for _ in range(trials):
+            i = vis[rng.integers(len(vis))]
+            j = rng.integers(base.shape[1])
+            eps = 1e-6 * max(np.abs(base[i]).max(), 1e-12) if inp in ("scales", "cov3D_precomp") else 1e-7
+            fd, fd2 = central(inp, base, i, j, eps), central(inp, base, i, j, eps / 4)
+            an = b[gname].reshape(P, -1)[i, j]
+            if abs(fd - fd2) > 1e-3 * max(abs(fd), abs(fd2), 1e-6):
+                continue  # the render is piecewise smooth (alpha / T / radius thresholds): a jump sits inside +-eps
+            checked += 1
+            tol = 5e-4 * max(abs(fd2), abs(an)) + 1e-5
+            assert abs(fd2 - an) <= tol, f"{inp}[{i},{j}]: finite difference {fd2} vs analytic {an}"
+        assert checked >= trials // 2, f"{inp}: too many finite-difference samples hit a discontinuity"
+
+
+def test_fd_gradients_deg0_scale_rot():
+    d = scene_inputs(P=1500, size=48, lsm=-4.5, seed=3, scale_modifier=1.3)
+    _fd_check(d, {"means3D": "dL_dmeans3D", "opacities": "dL_dopacity", "shs": "dL_dsh", "scales": "dL_dscales",
+                  "rotations": "dL_drots"})
+
+
+def test_fd_gradients_deg3():
+    d = scene_inputs(P=1500, size=48, lsm=-4.5, seed=5, sh_degree=3)
+    _fd_check(d, {"means3D": "dL_dmeans3D", "scales": "dL_dscales", "rotations": "dL_drots"}, trials=6)
+
+
+def test_fd_gradients_cov3d_and_colors():
+    d = scene_inputs(P=1500, size=48, lsm=-4.5, seed=7, use_cov=True, use_colors=True)
+    _fd_check(d, {"means3D": "dL_dmeans3D", "cov3D_precomp": "dL_dcov3D", "colors_precomp": "dL_dcolors",
+                  "opacities": "dL_dopacity"}, trials=6)
+
+
+def test_integer_stage_properties():
+    d = scene_inputs(P=6000, size=96, lsm=-4.0, width=96, height=80)
+    f = run_oracle(d, stop_after="binning")
+    R = f["num_rendered"]
+    assert R == int(f["tiles_touched"].astype(np.int64).sum()) == int(f["point_offsets"][-1])
+    assert ((f["radii"] > 0) == (f["tiles_touched"] > 0)).all()
+    keys, vals = f["keys"], f["point_list"]
+    assert (np.diff(keys.astype(np.uint64)) >= 0).all() if R > 1 else True   # sorted
+    # stable: equal keys keep ascending emission order == ascending Gaussian index inside a tile
+    same = keys[1:] == keys[:-1]
+    assert (vals[1:][same] > vals[:-1][same]).all()
+    # multiset preserved
+    assert np.array_equal(np.sort(f["list_unsorted"]), np.sort(vals))
+    # depth bits in the key equal the fp32 depth of the referenced Gaussian
+    assert np.array_equal((keys & np.uint64(0xFFFFFFFF)).astype(np.uint32), f["depths"][vals].view(np.uint32))
+    # ranges partition [0, R) by tile
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    rng = f["ranges"].astype(np.int64)
+    assert (rng[:, 1] - rng[:, 0]).sum() == R
+    for t in np.unique(tiles):
+        lo, hi = rng[t]
+        assert (tiles[lo:hi] == t).all() and (lo == 0 or tiles[lo - 1] != t) and (hi == R or tiles[hi] != t)
+    empty = np.setdiff1d(np.arange(f["T"]), np.unique(tiles))
+    assert (rng[empty] == 0).all()
+
+
+def test_oracle_edge_cases():
+    # P = 0
+    d = scene_inputs(P=0, size=32)
+    f = run_oracle(d)
+    assert f["num_rendered"] == 0
+    np.testing.assert_allclose(f["color"], np.broadcast_to(d["bg"].numpy()[:, None, None], (3, 32, 32)))
+    # a point exactly at the cull plane z = 0.2 is culled (t.z <= 0.2)
+    import torch
+    d = scene_inputs(P=4, size=32, lsm=-3.0)
+    cam2w = torch.inverse(d["viewmatrix"].T)      # V^-1
+    pts = torch.tensor([[0, 0, 0.2, 1.0], [0, 0, 0.2001, 1.0], [0, 0, -1.0, 1.0], [0, 0, 1.0, 1.0]])
+    d["means3D"] = (cam2w @ pts.T).T[:, :3].contiguous()
+    f = run_oracle(d)
+    assert f["radii"][2] == 0 and f["radii"][3] > 0
+    # mark_visible agrees with the cull test
+    mv = O.mark_visible(d["means3D"].numpy(), d["viewmatrix"].numpy())
+    assert mv[3] and not mv[2]
+    # prefiltered = True with a culled point is an error (upstream traps)
+    np_ = lambda t: None if t is None else t.numpy()
+    with pytest.raises(RuntimeError):
+        O.forward(means3D=np_(d["means3D"]), opacities=np_(d["opacities"]), shs=np_(d["shs"]), scales=np_(d["scales"]),
+                  rotations=np_(d["rotations"]), viewmatrix=np_(d["viewmatrix"]), projmatrix=np_(d["projmatrix"]),
+                  campos=np_(d["campos"]), bg=np_(d["bg"]), W=32, H=32, tanfovx=d["tanfovx"], tanfovy=d["tanfovy"],
+                  prefiltered=True)
