@@ -95,6 +95,10 @@ def main():
     ap.add_argument("--workload", default="1M_1024_cube", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backward", action="store_true", help="also time forward+backward (reported under 'extra')")
+    ap.add_argument("--no-train", action="store_true", help="skip the data-parallel train-step section")
+    ap.add_argument("--train-iters", type=int, default=8)
+    ap.add_argument("--train-points", type=int, default=500_000, help="positions per scene (reference: 500 000)")
+    ap.add_argument("--scenes-per-gpu", type=int, default=4)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,6 +186,34 @@ def main():
             stage_ms[k] = v / nprof
     ctx.set_profiling(False)
 
+    # ---- data-parallel decoder train step (BASELINE configs 3/5): scenes_per_gpu scenes per rank, 512x512,
+    #      decoder MLPs -> activations -> raster fwd -> L1+L2 -> bwd -> ONE flat RCCL all-reduce -> Adam
+    train = None
+    if not args.no_train:
+        from gaussian_gan_decoder_amd.train import DecoderTrainer, make_scene_batch
+        spg = args.scenes_per_gpu
+        tr = DecoderTrainer(dev, n_scenes_total=spg * world, image_size=512)
+        my_scenes = list(range(rank * spg, (rank + 1) * spg))
+        batches = [make_scene_batch(my_scenes, args.train_points, 512, dev, seed=i) for i in range(2)]
+        for i in range(2):
+            tr.step(batches[i % 2])
+        barrier()
+        tt = time.perf_counter()
+        for i in range(args.train_iters):
+            tr.step(batches[i % 2])
+        barrier()
+        t_train = time.perf_counter() - tt
+        if dist is not None:
+            t = torch.tensor([t_train], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_train = float(t.item())
+        nparam = sum(p.numel() for p in tr.params)
+        train = {"iters_per_s": args.train_iters / t_train, "scenes_per_s": args.train_iters * spg * world / t_train,
+                 "ms_per_iter": t_train / args.train_iters * 1e3, "global_batch": spg * world,
+                 "scenes_per_gpu": spg, "points_per_scene": args.train_points, "image": "512x512",
+                 "allreduce_bytes": nparam * 4 if world > 1 else 0,
+                 "step": "decoder MLPs (PyTorch fp32) -> activations -> HIP raster fwd -> L1+L2 -> bwd -> flat all-reduce -> Adam"}
+        del tr, batches
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -218,6 +250,8 @@ def main():
         "whole_frame": {"algorithmic_bytes": whole, "GBps": whole / (ms_per_step * 1e-3) / 1e9,
                         "frac_of_hbm_peak": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
+    if train is not None:
+        result["train"] = train
     if extra:
         result["extra"] = extra
     if not args.no_cpu_baseline:

@@ -17,7 +17,7 @@ EXPORTS = [
     "ggd_geom_bytes", "ggd_binning_bytes", "ggd_img_bytes", "ggd_geom_layout", "ggd_binning_layout",
     "ggd_img_layout", "ggd_sort_bits", "ggd_create", "ggd_destroy", "ggd_last_error", "ggd_version",
     "ggd_forward_geometry", "ggd_forward_render", "ggd_backward", "ggd_mark_visible", "ggd_debug_unsorted",
-    "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
+    "ggd_set_option", "ggd_get_option", "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
 ]
 
 
@@ -41,6 +41,7 @@ class ImgView(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("ranges", "final_T", "n_contrib", "total")]
 
 
+OPT_EXP_MODE, OPT_BLEND_CULL = 0, 1
 SPLAT_BYTES = 48
 SPLAT_FIELDS = ("x", "y", "conA", "conB", "conC", "opacity", "r", "g", "b", "depth", "radius", "tiles_touched")
 
@@ -77,6 +78,8 @@ def load():
         lib.ggd_backward.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 6 + [vp, vp, vp, vp, i64, vp] + [vp] * 8
         lib.ggd_mark_visible.argtypes = [vp, vp, i32, vp, vp, vp, vp]
         lib.ggd_debug_unsorted.argtypes = [vp, vp, vp, vp, i64]
+        lib.ggd_set_option.argtypes = [vp, C.c_int, C.c_int]
+        lib.ggd_get_option.argtypes = [vp, C.c_int]
         lib.ggd_set_profiling.argtypes = [vp, C.c_int]
         lib.ggd_stage_name.restype = C.c_char_p; lib.ggd_stage_name.argtypes = [C.c_int]
         lib.ggd_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
@@ -101,6 +104,9 @@ class Context:
     def check(self, rc: int):
         if rc != 0:
             raise RasterError(f"ggd error {rc}: " + self.lib.ggd_last_error(self.handle).decode())
+
+    def set_option(self, option: int, value: int):
+        self.check(self.lib.ggd_set_option(self.handle, int(option), int(value)))
 
     def set_profiling(self, on: bool):
         self.check(self.lib.ggd_set_profiling(self.handle, int(bool(on))))

@@ -38,6 +38,30 @@ __device__ __forceinline__ TileGeom tile_geom(int gx, const uint32_t* __restrict
   return g;
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));  // -> v_pk_{add,mul}_f32: two pixels per VALU issue
+
+// exp() variants for the blend (GGD_OPT_EXP_MODE).
+template <int MODE>
+__device__ __forceinline__ float blend_exp(float x) {
+  if (MODE == 1) return __expf(x);  // v_exp_f32(x * log2e): ~3 ulp on [-6, 0]
+  if (MODE == 2) {                  // 2^(hi) * (1 + lo*ln2): hi = fl(x*log2e), lo = exact product residual + low bits
+    const float t = x * 1.44269502162933349609375f;
+    float lo = __builtin_fmaf(x, 1.44269502162933349609375f, -t);
+    lo = __builtin_fmaf(x, 1.925963033500011e-08f, lo);
+    const float e = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(e, lo * 0.693147182464599609375f, e);
+  }
+  return expf(x);                   // ocml, <= 1 ulp
+}
+
+// One wave = one 16x16 tile, 4 horizontally adjacent pixels per lane.  Per staged record:
+//   (1) the four `power` values with packed fp32 math (operation order == the algorithm's published form),
+//   (2) CULL: if no pixel of the tile can reach alpha >= 1/255 -- tested in the power domain against a per-record
+//       threshold ln(1/(255*opacity)) lowered by a safety margin, so the decision is exact w.r.t. the float alpha
+//       test that follows -- the whole wave skips the record with one ballot, before any exp,
+//   (3) the exact per-pixel tests and the blend update.
+// A finished pixel gets x = +inf: its power becomes -inf/NaN and it drops out in (2) with no extra instructions.
+template <int EXP_MODE, bool CULL>
 __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx, const ggd_splat* __restrict__ splat,
                                                            const uint32_t* __restrict__ list,
                                                            const uint32_t* __restrict__ ranges,
@@ -49,16 +73,20 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
   const int lane = threadIdx.x;
   const TileGeom g = tile_geom(gx, ranges);
   const bool row_in = g.py < H;
-  float pxf[4], T[4], C[4][3];
+  const float INF = __builtin_huge_valf();
+  float T[4], C[4][3];
   uint32_t last[4];
-  bool done[4];
+  f2 pxA, pxB;  // pixel x coordinates (0,1) and (2,3); +inf once the pixel is finished / outside the image
+  int alive = 0;
   const float pyf = (float)g.py;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    pxf[k] = (float)(g.px0 + k);
     T[k] = 1.0f; C[k][0] = C[k][1] = C[k][2] = 0.0f;
     last[k] = 0;
-    done[k] = !(row_in && (g.px0 + k) < W);
+    const bool in = row_in && (g.px0 + k) < W;
+    alive += in ? 1 : 0;
+    const float x = in ? (float)(g.px0 + k) : INF;
+    if (k == 0) pxA.x = x; else if (k == 1) pxA.y = x; else if (k == 2) pxB.x = x; else pxB.y = x;
   }
 
   float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
@@ -66,10 +94,13 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
     if (pos < g.hi) {
       const float4* p = reinterpret_cast<const float4*>(splat + list[pos]);
       r0 = p[0]; r1 = p[1]; r2 = p[2];
+      // record slot 2 is re-used for the blend: {b, power threshold, -, -}
+      const float L = logf(1.0f / (255.0f * r1.y));
+      r2.y = CULL ? L - (2e-5f + 1e-6f * fabsf(L)) : -INF;
     }
   };
   fetch(g.lo + lane);
-  bool finished = false;
+  bool finished = __ballot(alive != 0) == 0ull;
   for (uint32_t base = g.lo; base < g.hi && !finished; base += 64) {
     __syncthreads();  // single-wave block: orders the previous round's LDS reads before this round's writes
     s_rec[lane * 3 + 0] = r0; s_rec[lane * 3 + 1] = r1; s_rec[lane * 3 + 2] = r2;
@@ -78,30 +109,43 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
     const int n = (int)min(64u, g.hi - base);
     const uint32_t cbase = base - g.lo;
     for (int j = 0; j < n; ++j) {
-      if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) { finished = true; break; }
+      if ((j & 7) == 0 && __ballot(alive != 0) == 0ull) { finished = true; break; }
       const float4 a = s_rec[j * 3 + 0];  // x, y, conA, conB
       const float4 b = s_rec[j * 3 + 1];  // conC, opacity, r, g
-      const float cb = s_rec[j * 3 + 2].x;
-      const uint32_t contributor = cbase + (uint32_t)j + 1u;
+      const float2 c = *reinterpret_cast<const float2*>(&s_rec[j * 3 + 2]);  // b, power threshold
       const float dy = a.y - pyf;
       const float cdy2 = b.x * dy * dy;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float dx = a.x - pxf[k];
-        const float power = -0.5f * (a.z * dx * dx + cdy2) - a.w * dx * dy;
-        const float alpha = fminf(0.99f, b.y * expf(power));
-        const bool live = !done[k] && !(power > 0.0f) && !(alpha < ALPHA_FLOOR);
-        const float test_T = T[k] * (1.0f - alpha);
-        const bool stop = live && (test_T < 0.0001f);
-        done[k] = done[k] || stop;
-        if (live && !stop) {
-          C[k][0] += b.z * alpha * T[k];
-          C[k][1] += b.w * alpha * T[k];
-          C[k][2] += cb * alpha * T[k];
-          T[k] = test_T;
-          last[k] = contributor;
-        }
+      const f2 gxx = {a.x, a.x};
+      const f2 dxA = gxx - pxA, dxB = gxx - pxB;
+      const f2 powA = -0.5f * (a.z * dxA * dxA + cdy2) - a.w * dxA * dy;
+      const f2 powB = -0.5f * (a.z * dxB * dxB + cdy2) - a.w * dxB * dy;
+      const bool n0 = powA.x >= c.y, n1 = powA.y >= c.y, n2 = powB.x >= c.y, n3 = powB.y >= c.y;
+      if (__ballot(n0 || n1 || n2 || n3) == 0ull) continue;
+      const uint32_t contributor = cbase + (uint32_t)j + 1u;
+#define GGD_PIXEL(k, POWER, NEED, PX)                                                        \
+      {                                                                                      \
+        const float power = POWER;                                                           \
+        const float alpha = fminf(0.99f, b.y * blend_exp<EXP_MODE>(power));                  \
+        const bool live = (NEED) && !(power > 0.0f) && !(alpha < ALPHA_FLOOR);               \
+        const float test_T = T[k] * (1.0f - alpha);                                          \
+        if (live) {                                                                          \
+          if (test_T < 0.0001f) {                                                            \
+            PX = INF;                                                                        \
+            alive -= 1;                                                                      \
+          } else {                                                                           \
+            C[k][0] += b.z * alpha * T[k];                                                   \
+            C[k][1] += b.w * alpha * T[k];                                                   \
+            C[k][2] += c.x * alpha * T[k];                                                   \
+            T[k] = test_T;                                                                   \
+            last[k] = contributor;                                                           \
+          }                                                                                  \
+        }                                                                                    \
       }
+      GGD_PIXEL(0, powA.x, n0, pxA.x)
+      GGD_PIXEL(1, powA.y, n1, pxA.y)
+      GGD_PIXEL(2, powB.x, n2, pxB.x)
+      GGD_PIXEL(3, powB.y, n3, pxB.y)
+#undef GGD_PIXEL
     }
   }
 
@@ -132,6 +176,7 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
   }
 }
 
+template <int EXP_MODE, bool CULL>
 __global__ __launch_bounds__(64) void blend_backward_kernel(
     int W, int H, int gx, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ list,
     const uint32_t* __restrict__ ranges, const float* __restrict__ bg, const float* __restrict__ final_T,
@@ -145,7 +190,8 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
   const size_t HW = (size_t)H * W;
   const size_t pix0 = (size_t)g.py * W + g.px0;
 
-  float pxf[4], T[4], Tfin[4], gpx[4][3], acc[4][3], lastc[4][3], last_alpha[4], bgdot[4];
+  float T[4], Tfin[4], gpx[4][3], acc[4][3], lastc[4][3], last_alpha[4], bgdot[4];
+  const f2 pxA = {(float)g.px0, (float)(g.px0 + 1)}, pxB = {(float)(g.px0 + 2), (float)(g.px0 + 3)};
   uint32_t lastn[4];
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const float pyf = (float)g.py;
@@ -153,7 +199,6 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const bool in = row_in && (g.px0 + k) < W;
-    pxf[k] = (float)(g.px0 + k);
     Tfin[k] = in ? final_T[pix0 + k] : 0.0f;
     T[k] = Tfin[k];
     lastn[k] = in ? n_contrib[pix0 + k] : 0u;
@@ -181,7 +226,11 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
     if (lane < n) {
       my_id = list[cstart + lane];
       const float4* p = reinterpret_cast<const float4*>(splat + my_id);
-      s_rec[lane * 3 + 0] = p[0]; s_rec[lane * 3 + 1] = p[1]; s_rec[lane * 3 + 2] = p[2];
+      const float4 q1 = p[1];
+      float4 q2 = p[2];
+      const float L = logf(1.0f / (255.0f * q1.y));  // same conservative power-domain threshold as the forward
+      q2.y = CULL ? L - (2e-5f + 1e-6f * fabsf(L)) : -__builtin_huge_valf();
+      s_rec[lane * 3 + 0] = p[0]; s_rec[lane * 3 + 1] = q1; s_rec[lane * 3 + 2] = q2;
     }
     __syncthreads();
     uint64_t touched = 0;
@@ -189,19 +238,29 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
       const uint32_t pos0 = (cstart - g.lo) + (uint32_t)j;  // 0-based position in the tile's list
       const float4 a = s_rec[j * 3 + 0];
       const float4 b = s_rec[j * 3 + 1];
-      const float cb = s_rec[j * 3 + 2].x;
-      const float col[3] = {b.z, b.w, cb};
+      const float2 c2 = *reinterpret_cast<const float2*>(&s_rec[j * 3 + 2]);  // b, power threshold
+      const float col[3] = {b.z, b.w, c2.x};
       const float dy = a.y - pyf;
       const float cdy2 = b.x * dy * dy;
+      const f2 gxx = {a.x, a.x};
+      const f2 dxA = gxx - pxA, dxB = gxx - pxB;
+      const f2 powA = -0.5f * (a.z * dxA * dxA + cdy2) - a.w * dxA * dy;
+      const f2 powB = -0.5f * (a.z * dxB * dxB + cdy2) - a.w * dxB * dy;
+      const float dxs[4] = {dxA.x, dxA.y, dxB.x, dxB.y};
+      const float pows[4] = {powA.x, powA.y, powB.x, powB.y};
+      bool need[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) need[k] = (pos0 < lastn[k]) && (pows[k] >= c2.y);
+      if (__ballot(need[0] || need[1] || need[2] || need[3]) == 0ull) continue;  // nobody in the tile saw it
       float s_col[3] = {0.f, 0.f, 0.f}, s_op = 0.f, s_cA = 0.f, s_cB = 0.f, s_cC = 0.f, s_mx = 0.f, s_my = 0.f;
       bool any = false;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float dx = a.x - pxf[k];
-        const float power = -0.5f * (a.z * dx * dx + cdy2) - a.w * dx * dy;
-        const float G = expf(power);
+        const float dx = dxs[k];
+        const float power = pows[k];
+        const float G = blend_exp<EXP_MODE>(power);
         const float alpha = fminf(0.99f, b.y * G);
-        const bool live = (pos0 < lastn[k]) && !(power > 0.0f) && !(alpha < ALPHA_FLOOR);
+        const bool live = need[k] && !(power > 0.0f) && !(alpha < ALPHA_FLOOR);
         if (live) {
           any = true;
           T[k] = T[k] / (1.0f - alpha);
@@ -266,8 +325,17 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
                      uint32_t* n_contrib) {
   const int gx = (prm.width + 15) / 16, gy = (prm.height + 15) / 16;
   if (gx * gy == 0) return GGD_OK;
-  hipLaunchKernelGGL(blend_forward_kernel, dim3(gx * gy), dim3(64), 0, s, prm.width, prm.height, gx, splat, list,
-                     ranges, prm.bg, out_color, final_T, n_contrib);
+  const int em = ctx->opt[GGD_OPT_EXP_MODE];
+  const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
+#define GGD_LAUNCH_FWD(EM, CU)                                                                                   \
+  hipLaunchKernelGGL((blend_forward_kernel<EM, CU>), dim3(gx * gy), dim3(64), 0, s, prm.width, prm.height, gx,  \
+                     splat, list, ranges, prm.bg, out_color, final_T, n_contrib)
+  if (cull) {
+    if (em == 0) GGD_LAUNCH_FWD(0, true); else if (em == 1) GGD_LAUNCH_FWD(1, true); else GGD_LAUNCH_FWD(2, true);
+  } else {
+    if (em == 0) GGD_LAUNCH_FWD(0, false); else if (em == 1) GGD_LAUNCH_FWD(1, false); else GGD_LAUNCH_FWD(2, false);
+  }
+#undef GGD_LAUNCH_FWD
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }
@@ -278,8 +346,18 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
                               float* dL_dconic, float* dL_dopacity, float* dL_dcolors) {
   const int gx = (prm.width + 15) / 16, gy = (prm.height + 15) / 16;
   if (gx * gy == 0) return GGD_OK;
-  hipLaunchKernelGGL(blend_backward_kernel, dim3(gx * gy), dim3(64), 0, s, prm.width, prm.height, gx, splat, list,
-                     ranges, prm.bg, final_T, n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors);
+  const int em = ctx->opt[GGD_OPT_EXP_MODE];
+  const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
+#define GGD_LAUNCH_BWD(EM, CU)                                                                                    \
+  hipLaunchKernelGGL((blend_backward_kernel<EM, CU>), dim3(gx * gy), dim3(64), 0, s, prm.width, prm.height, gx,  \
+                     splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, \
+                     dL_dcolors)
+  if (cull) {
+    if (em == 0) GGD_LAUNCH_BWD(0, true); else if (em == 1) GGD_LAUNCH_BWD(1, true); else GGD_LAUNCH_BWD(2, true);
+  } else {
+    if (em == 0) GGD_LAUNCH_BWD(0, false); else if (em == 1) GGD_LAUNCH_BWD(1, false); else GGD_LAUNCH_BWD(2, false);
+  }
+#undef GGD_LAUNCH_BWD
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }

@@ -3,6 +3,7 @@
 // Stage sequence of one forward: preprocess -> inclusive scan -> read back R ->
 // duplicateWithKeys -> stable radix sort -> tile ranges -> blend.  The one host sync is the read-back of
 // R = num_rendered, exactly where the CUDA original has it; everything else is enqueued on the caller's stream.
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -97,6 +98,8 @@ extern "C" ggd_ctx* ggd_create(int device) {
   ggd_ctx* ctx = new (std::nothrow) ggd_ctx();
   if (!ctx) { ggd_fail(nullptr, GGD_E_NOMEM, "out of host memory"); return nullptr; }
   ctx->device = device;
+  if (const char* e = getenv("GGD_EXP_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->opt[GGD_OPT_EXP_MODE] = v; }
+  if (const char* e = getenv("GGD_BLEND_CULL")) ctx->opt[GGD_OPT_BLEND_CULL] = atoi(e) != 0;
   int prev = 0;
   (void)hipGetDevice(&prev);
   bool ok = hipSetDevice(device) == hipSuccess &&
@@ -126,6 +129,19 @@ extern "C" void ggd_destroy(ggd_ctx* ctx) {
 }
 
 extern "C" const char* ggd_last_error(ggd_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
+  if (!ctx) return GGD_E_INVALID;
+  static const int kMax[GGD_OPT_COUNT] = {2, 1};
+  if (option < 0 || option >= GGD_OPT_COUNT || value < 0 || value > kMax[option])
+    return ggd_fail(ctx, GGD_E_INVALID, "ggd_set_option: unknown option or value");
+  ctx->opt[option] = value;
+  return GGD_OK;
+}
+extern "C" int ggd_get_option(ggd_ctx* ctx, int option) {
+  if (!ctx || option < 0 || option >= GGD_OPT_COUNT) return GGD_E_INVALID;
+  return ctx->opt[option];
+}
 
 extern "C" int ggd_set_profiling(ggd_ctx* ctx, int enabled) {
   if (!ctx) return GGD_E_INVALID;

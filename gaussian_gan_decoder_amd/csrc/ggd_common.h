@@ -29,6 +29,7 @@ struct ggd_ctx {
   void* dbg_keys = nullptr;     // debug copy of the unsorted list
   void* dbg_vals = nullptr;
   size_t dbg_cap = 0;
+  int opt[GGD_OPT_COUNT] = {0, 1};
   bool profiling = false;
   hipEvent_t ev[2 * ST_COUNT] = {};
   bool ev_used[ST_COUNT] = {};

@@ -160,6 +160,17 @@ int ggd_mark_visible(ggd_ctx* ctx, void* stream, int32_t P, const float* means3D
  * to device buffers keys[R] / values[R] supplied by the caller.  Either pointer may be NULL. */
 int ggd_debug_unsorted(ggd_ctx* ctx, void* stream, uint64_t* keys, uint32_t* values, int64_t num_rendered);
 
+/* Tuning / experiment knobs (do not change results beyond the documented tolerances).  Returns GGD_E_INVALID for an
+ * unknown option or value. */
+enum {
+  GGD_OPT_EXP_MODE = 0,   /* blend exp(): 0 = ocml expf (<=1 ulp, default), 1 = native 2^(x*log2e) (fast, ~3 ulp),
+                             2 = compensated 2^x (v_exp_f32 + product-residual correction, ~1 ulp) */
+  GGD_OPT_BLEND_CULL = 1, /* 1 (default) = skip records whose alpha cannot reach 1/255 anywhere in the tile */
+  GGD_OPT_COUNT
+};
+int ggd_set_option(ggd_ctx* ctx, int option, int value);
+int ggd_get_option(ggd_ctx* ctx, int option);
+
 /* Per-stage device time (ms, hipEvent pairs on `stream`) of the most recent forward_geometry / forward_render /
  * backward call when profiling is on.  Stage names: ggd_stage_name(i), i in [0, ggd_stage_count()). */
 int ggd_set_profiling(ggd_ctx* ctx, int enabled);

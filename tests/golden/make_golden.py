@@ -96,6 +96,26 @@ def cov3d():
     return dict(scales=L(s), rotations=L(q), cases=out)
 
 
+def decoder_fixture():
+    """Config-1 plumbing (BASELINE.json configs[0]): the reference's 2-D tri-plane sampler
+    (eg3d/training/volumetric_rendering/renderer.py:23-65) and per-point Decoder MLP
+    (main/decoder_models/base_decoder.py:8-27) on seeded inputs."""
+    sys.path.insert(0, os.path.join(REF, "eg3d"))
+    from training.volumetric_rendering.renderer import sample_from_planes, generate_planes
+    from decoder_models.base_decoder import Decoder
+    g = torch.Generator().manual_seed(21)
+    planes = torch.randn(3, 8, 16, 16, generator=g)
+    pos = torch.rand(40, 3, generator=g) - 0.5
+    pf = sample_from_planes(generate_planes(), planes.unsqueeze(0), pos.unsqueeze(0), padding_mode="zeros", box_warp=1)[0]
+    torch.manual_seed(22)
+    dec = Decoder(n_features=8 + 3, out_features=4, hidden_dim=16)
+    out = dec(pf, pos)
+    sd = {"sd_" + k: v.numpy() for k, v in dec.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "decoder_fixture.npz"), planes=planes.numpy(), positions=pos.numpy(),
+                        plane_features=pf.numpy(), decoder_out=out.detach().numpy(), n_features=11, out_features=4,
+                        hidden_dim=16, **sd)
+
+
 def oracle_regression():
     from oracle import ggd_oracle as O
     from gaussian_gan_decoder_amd.synthetic import make_scene, make_dL_dpix
@@ -117,5 +137,6 @@ if __name__ == "__main__":
     for name, fn in (("cameras", cameras), ("sh", sh), ("cov3d", cov3d)):
         with open(os.path.join(HERE, name + ".json"), "w") as fh:
             json.dump(fn(), fh)
+    decoder_fixture()
     oracle_regression()
     print("wrote", sorted(os.listdir(HERE)))
