@@ -30,7 +30,7 @@ class Params(C.Structure):
 
 
 class GeomView(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("splat", "tiles_touched", "point_offsets", "clamped", "total")]
+    _fields_ = [(n, C.c_size_t) for n in ("splat", "tiles_touched", "point_offsets", "clamped", "depth_keys", "header", "total")]
 
 
 class BinningView(C.Structure):
@@ -41,7 +41,7 @@ class ImgView(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("ranges", "final_T", "n_contrib", "total")]
 
 
-OPT_EXP_MODE, OPT_BLEND_CULL = 0, 1
+OPT_EXP_MODE, OPT_BLEND_CULL, OPT_BINNING = 0, 1, 2
 SPLAT_BYTES = 48
 SPLAT_FIELDS = ("x", "y", "conA", "conB", "conC", "opacity", "r", "g", "b", "depth", "radius", "tiles_touched")
 

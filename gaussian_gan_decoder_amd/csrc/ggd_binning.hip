@@ -197,55 +197,94 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int W, int H, con
 }
 
 // ----------------------------------------------------------------------------------------------- radix sort ---
+// "Onesweep" LSD radix sort: ONE kernel per 8-bit digit pass (+ one up-front kernel that histograms every digit).
+//   * global digit histograms are permutation-invariant, so all passes' bin bases come from one read of the keys;
+//   * inside a pass every 4096-pair tile computes its digit counts, publishes them, and obtains the sum over all
+//     EARLIER tiles by decoupled look-back: a 32-bit status word per (tile, digit) = 2 flag bits | 30-bit count,
+//     written/read as single agent-scope relaxed atomics (the value IS the flag, so no fence is needed and the
+//     protocol is placement independent: per-XCD L2s are not coherent, agent-scope atomics bypass them);
+//     tiles take their index from an atomic ticket, so a tile only ever waits for tiles that are already running;
+//   * stability: element order inside a tile = (wave, round, lane); rank inside a wave by ballot matching.
 constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 16;                      // keys per lane
-constexpr int RS_TILE = RS_THREADS * RS_ITEMS;    // 4096 pairs per block
-constexpr int RS_WAVE_TILE = 64 * RS_ITEMS;       // 1024 consecutive pairs per wave
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;    // 4096 pairs per tile
 constexpr int RS_BINS = 256;
+constexpr int RS_MAX_PASSES = 8;
+constexpr int RS32_ITEMS = 16;                   // tile size of the 32-bit (depth) sort (4 was slower: longer look-back)
+constexpr int RS32_TILE = RS_THREADS * RS32_ITEMS;
+constexpr uint32_t RS_FLAG_LOCAL = 1u << 30, RS_FLAG_INCL = 2u << 30, RS_COUNT_MASK = (1u << 30) - 1u;
 
-// hist[digit * nblk + blk] = number of keys of block `blk` whose digit (bits [shift, shift+8)) equals `digit`.
-__global__ __launch_bounds__(RS_THREADS) void sort_hist_kernel(const uint64_t* __restrict__ keys, int64_t n,
-                                                               int shift, uint32_t* __restrict__ hist, int nblk) {
-  __shared__ uint32_t s_hist[RS_BINS];
-  s_hist[threadIdx.x] = 0;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
-#pragma unroll 4
-  for (int k = 0; k < RS_ITEMS; ++k) {
-    const int64_t idx = base + (int64_t)k * RS_THREADS + threadIdx.x;
-    if (idx < n) atomicAdd(&s_hist[(uint32_t)(keys[idx] >> shift) & 0xffu], 1u);
-  }
-  __syncthreads();
-  hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
+__device__ __forceinline__ uint32_t rs_load(uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void rs_store(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Stable scatter.  Element order inside a block = (wave, round, lane): wave w owns the contiguous 1024 pairs
-// [blk*4096 + w*1024, +1024) and visits them 64 at a time, lane l <-> element round*64 + l.
-__global__ __launch_bounds__(RS_THREADS) void sort_scatter_kernel(const uint64_t* __restrict__ keys_in,
-                                                                  const uint32_t* __restrict__ vals_in,
-                                                                  uint64_t* __restrict__ keys_out,
-                                                                  uint32_t* __restrict__ vals_out, int64_t n,
-                                                                  int shift, const uint32_t* __restrict__ hist_ex,
-                                                                  int nblk) {
-  __shared__ uint32_t s_cnt[4][RS_BINS];   // per-wave running digit counts -> per-wave exclusive bases
+// ghist[pass * 256 + digit] += occurrences, for every pass at once.  High key bytes are heavily skewed (tile bits of
+// consecutive instances, exponent byte of the depth): when a whole wave shares the digit one lane adds the count
+// instead of 64 conflicting LDS atomics.
+template <typename KeyT, int ITEMS>
+__global__ __launch_bounds__(RS_THREADS) void sort_global_hist_kernel(const KeyT* __restrict__ keys, int64_t n,
+                                                                      int passes, uint32_t* __restrict__ ghist) {
+  __shared__ uint32_t s_hist[RS_MAX_PASSES * RS_BINS];
+  for (int b = threadIdx.x; b < passes * RS_BINS; b += RS_THREADS) s_hist[b] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * (RS_THREADS * ITEMS);
+  const int lane = threadIdx.x & 63;
+#pragma unroll 4
+  for (int k = 0; k < ITEMS; ++k) {
+    const int64_t idx = base + (int64_t)k * RS_THREADS + threadIdx.x;
+    const bool ok = idx < n;
+    const KeyT key = ok ? keys[idx] : (KeyT)0;
+    const uint64_t act = __ballot(ok);
+    if (act == 0ull) continue;
+    const int leader = __builtin_ctzll(act);
+    for (int p = 0; p < passes; ++p) {
+      const uint32_t d = (uint32_t)(key >> (8 * p)) & 0xffu;
+      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
+      if (__ballot(ok && d != d0) == 0ull) {
+        if (lane == leader) atomicAdd(&s_hist[p * RS_BINS + d0], (uint32_t)__popcll(act));
+      } else if (ok) {
+        atomicAdd(&s_hist[p * RS_BINS + d], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < passes * RS_BINS; b += RS_THREADS) {
+    const uint32_t c = s_hist[b];
+    if (c) atomicAdd(&ghist[b], c);
+  }
+}
+
+template <typename KeyT, bool IOTA, int ITEMS>
+__global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
+    const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, int64_t n, int shift, const uint32_t* __restrict__ ghist /*[256] of this pass*/,
+    uint32_t* status /*[ntiles][256]*/, uint32_t* ticket) {
+  __shared__ uint32_t s_cnt[4][RS_BINS];   // per-wave running digit counts -> per-wave scatter bases
+  __shared__ uint32_t s_scan[4];
+  __shared__ uint32_t s_tile;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
   for (int b = threadIdx.x; b < 4 * RS_BINS; b += RS_THREADS) (&s_cnt[0][0])[b] = 0;
   __syncthreads();
+  const uint32_t tile = s_tile;
 
-  const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)wv * RS_WAVE_TILE;
-  uint64_t key[RS_ITEMS];
-  uint32_t val[RS_ITEMS];
-  uint32_t rank[RS_ITEMS];
+  const int64_t wbase = (int64_t)tile * (RS_THREADS * ITEMS) + (int64_t)wv * (64 * ITEMS);
+  KeyT key[ITEMS];
+  uint32_t val[ITEMS];
+  uint32_t rank[ITEMS];
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const int64_t idx = wbase + r * 64 + lane;
     const bool ok = idx < n;
-    key[r] = ok ? keys_in[idx] : ~0ull;
-    val[r] = ok ? vals_in[idx] : 0u;
+    key[r] = ok ? keys_in[idx] : (KeyT)~(KeyT)0;
+    val[r] = IOTA ? (uint32_t)idx : (ok ? vals_in[idx] : 0u);
   }
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const int64_t idx = wbase + r * 64 + lane;
     const bool ok = idx < n;
     const uint32_t d = (uint32_t)(key[r] >> shift) & 0xffu;
@@ -258,26 +297,53 @@ __global__ __launch_bounds__(RS_THREADS) void sort_scatter_kernel(const uint64_t
     const uint32_t before = s_cnt[wv][d];  // all peers read the same word (LDS broadcast)
     const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
     rank[r] = before + below;
-    // wave-synchronous: every peer has read `before` before the leader updates it (same instruction stream)
-    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();       // every peer has read `before` before the leader updates it
     if (ok && below == 0) s_cnt[wv][d] = before + (uint32_t)__popcll(peers);
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  // per digit: turn the 4 per-wave totals into exclusive bases and add the global (digit, block) offset
   {
+    // thread d owns digit d: tile-local count, look-back over earlier tiles, global base
     const int d = threadIdx.x;
-    uint32_t run = hist_ex[(size_t)d * nblk + blockIdx.x];
+    const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
+    const uint32_t local = c0 + c1 + c2 + c3;
+    uint32_t* my = status + (size_t)tile * RS_BINS + d;
+    uint32_t excl = 0;
+    if (tile == 0) {
+      rs_store(my, RS_FLAG_INCL | local);
+    } else {
+      rs_store(my, RS_FLAG_LOCAL | local);
+      // look-back, 8 predecessors per round trip (independent loads in flight together)
+      int64_t t = (int64_t)tile - 1;
+      bool done = false;
+      while (!done) {
+        uint32_t v[8];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const uint32_t c = s_cnt[w][d];
-      s_cnt[w][d] = run;
-      run += c;
+        for (int i = 0; i < 8; ++i) v[i] = (t - i >= 0) ? rs_load(status + (size_t)(t - i) * RS_BINS + d) : RS_FLAG_INCL;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (!done) {
+            uint32_t x = v[i];
+            if ((x >> 30) == 0u) {  // not published yet: poll this one
+              uint32_t* p = status + (size_t)(t - i) * RS_BINS + d;
+              do { __builtin_amdgcn_s_sleep(1); x = rs_load(p); } while ((x >> 30) == 0u);
+            }
+            excl += x & RS_COUNT_MASK;
+            if ((x >> 30) == 2u) done = true;
+          }
+        }
+        t -= 8;
+      }
+      rs_store(my, RS_FLAG_INCL | (excl + local));
     }
+    uint32_t tot;
+    const uint32_t gbase = block_exclusive_scan_256(ghist[d], &tot, s_scan);  // contains __syncthreads
+    const uint32_t base = gbase + excl;
+    s_cnt[0][d] = base; s_cnt[1][d] = base + c0; s_cnt[2][d] = base + c0 + c1; s_cnt[3][d] = base + c0 + c1 + c2;
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const int64_t idx = wbase + r * 64 + lane;
     if (idx < n) {
       const uint32_t d = (uint32_t)(key[r] >> shift) & 0xffu;
@@ -330,38 +396,82 @@ int ggd_launch_duplicate(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, con
 static inline int sort_passes(int nbits) { return (nbits + 7) / 8; }
 int ggd_sort_input_is_alt(int nbits) { return sort_passes(nbits) & 1; }
 
+// tmp layout: [ghist: MAX_PASSES*256 u32][tickets: MAX_PASSES u32 (padded)][status: passes * ntiles * 256 u32]
+static inline size_t sort_ctrl_bytes() { return ggd_align((size_t)(RS_MAX_PASSES * RS_BINS + 64) * sizeof(uint32_t)); }
 size_t ggd_sort_tmp_bytes(int64_t n) {
-  const int64_t nblk = (n + RS_TILE - 1) / RS_TILE;
-  const int64_t cnt = (nblk > 0 ? nblk : 1) * RS_BINS;
-  return ggd_align((size_t)cnt * sizeof(uint32_t)) + ggd_scan_tmp_bytes(cnt);
+  const int64_t ntiles = (n + RS_TILE - 1) / RS_TILE;
+  return sort_ctrl_bytes() + ggd_align((size_t)RS_MAX_PASSES * (size_t)(ntiles > 0 ? ntiles : 1) * RS_BINS * sizeof(uint32_t));
 }
 
-int ggd_launch_sort(ggd_ctx* ctx, hipStream_t s, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b,
-                    uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes) {
+size_t ggd_sort32_tmp_bytes(int64_t n) {
+  const int64_t ntiles = (n + RS32_TILE - 1) / RS32_TILE;
+  return sort_ctrl_bytes() + ggd_align((size_t)4 * (size_t)(ntiles > 0 ? ntiles : 1) * RS_BINS * sizeof(uint32_t));
+}
+
+template <typename KeyT>
+static int launch_sort_t(ggd_ctx* ctx, hipStream_t s, KeyT* keys_a, uint32_t* vals_a, KeyT* keys_b, uint32_t* vals_b,
+                         int64_t n, int nbits, void* tmp, size_t tmp_bytes) {
   if (n <= 0) return GGD_OK;
-  if (tmp_bytes < ggd_sort_tmp_bytes(n)) return ggd_fail(ctx, GGD_E_INVALID, "sort tmp too small");
-  const int nblk = (int)((n + RS_TILE - 1) / RS_TILE);
-  const int64_t cnt = (int64_t)nblk * RS_BINS;
-  uint32_t* hist = static_cast<uint32_t*>(tmp);
-  void* scan_tmp = static_cast<char*>(tmp) + ggd_align((size_t)cnt * sizeof(uint32_t));
-  const size_t scan_tmp_bytes = ggd_scan_tmp_bytes(cnt);
   const int passes = sort_passes(nbits);
-  uint64_t* kin = (passes & 1) ? keys_b : keys_a;
+  if (passes > RS_MAX_PASSES) return ggd_fail(ctx, GGD_E_INVALID, "sort: too many key bits");
+  if (tmp_bytes < ggd_sort_tmp_bytes(n)) return ggd_fail(ctx, GGD_E_INVALID, "sort tmp too small");
+  const int ntiles = (int)((n + RS_TILE - 1) / RS_TILE);
+  uint32_t* ghist = static_cast<uint32_t*>(tmp);
+  uint32_t* tickets = ghist + RS_MAX_PASSES * RS_BINS;
+  uint32_t* status = reinterpret_cast<uint32_t*>(static_cast<char*>(tmp) + sort_ctrl_bytes());
+  const size_t status_bytes = (size_t)passes * ntiles * RS_BINS * sizeof(uint32_t);
+  GGD_HIP(hipMemsetAsync(tmp, 0, sort_ctrl_bytes() + status_bytes, s));   // histograms, tickets, status words
+  KeyT* kin = (passes & 1) ? keys_b : keys_a;
   uint32_t* vin = (passes & 1) ? vals_b : vals_a;
-  uint64_t* kout = (passes & 1) ? keys_a : keys_b;
+  KeyT* kout = (passes & 1) ? keys_a : keys_b;
   uint32_t* vout = (passes & 1) ? vals_a : vals_b;
+  hipLaunchKernelGGL((sort_global_hist_kernel<KeyT, RS_ITEMS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, n, passes,
+                     ghist);
   for (int p = 0; p < passes; ++p) {
-    const int shift = 8 * p;
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, kin, n, shift, hist, nblk);
-    const int rc = launch_scan<true>(ctx, s, hist, hist, cnt, nullptr, scan_tmp, scan_tmp_bytes);
-    if (rc != GGD_OK) return rc;
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, shift,
-                       hist, nblk);
-    uint64_t* tk = kin; kin = kout; kout = tk;
+    hipLaunchKernelGGL((sort_onesweep_kernel<KeyT, false, RS_ITEMS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n,
+                       8 * p, ghist + p * RS_BINS, status + (size_t)p * ntiles * RS_BINS, tickets + p);
+    KeyT* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
   }
   GGD_HIP(hipGetLastError());
   return GGD_OK;
+}
+
+int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
+                           uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes) {
+  if (n <= 0) return GGD_OK;
+  const int passes = sort_passes(nbits);
+  if (passes > RS_MAX_PASSES || (passes & 1)) return ggd_fail(ctx, GGD_E_INVALID, "sort32: need an even pass count");
+  if (tmp_bytes < ggd_sort32_tmp_bytes(n)) return ggd_fail(ctx, GGD_E_INVALID, "sort tmp too small");
+  const int ntiles = (int)((n + RS32_TILE - 1) / RS32_TILE);
+  uint32_t* ghist = static_cast<uint32_t*>(tmp);
+  uint32_t* tickets = ghist + RS_MAX_PASSES * RS_BINS;
+  uint32_t* status = reinterpret_cast<uint32_t*>(static_cast<char*>(tmp) + sort_ctrl_bytes());
+  const size_t status_bytes = (size_t)passes * ntiles * RS_BINS * sizeof(uint32_t);
+  GGD_HIP(hipMemsetAsync(tmp, 0, sort_ctrl_bytes() + status_bytes, s));
+  hipLaunchKernelGGL((sort_global_hist_kernel<uint32_t, RS32_ITEMS>), dim3(ntiles), dim3(RS_THREADS), 0, s, keys_src,
+                     n, passes, ghist);
+  // pass 0: keys_src (read-only, caller's buffer) -> B with identity values; then B -> A -> B -> A ...
+  const uint32_t* kin = keys_src;
+  const uint32_t* vin = nullptr;
+  for (int p = 0; p < passes; ++p) {
+    uint32_t* kout = (p & 1) ? keys_a : keys_b;
+    uint32_t* vout = (p & 1) ? vals_a : vals_b;
+    if (p == 0)
+      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, true, RS32_ITEMS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout,
+                         vout, n, 0, ghist, status, tickets);
+    else
+      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout,
+                         vout, n, 8 * p, ghist + p * RS_BINS, status + (size_t)p * ntiles * RS_BINS, tickets + p);
+    kin = kout; vin = vout;
+  }
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
+int ggd_launch_sort(ggd_ctx* ctx, hipStream_t s, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b,
+                    uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes) {
+  return launch_sort_t<uint64_t>(ctx, s, keys_a, vals_a, keys_b, vals_b, n, nbits, tmp, tmp_bytes);
 }
 
 int ggd_launch_ranges(ggd_ctx* ctx, hipStream_t s, const uint64_t* keys, int64_t n, uint32_t* ranges, int T) {

@@ -43,6 +43,8 @@ extern "C" int ggd_geom_layout(int32_t P, ggd_geom_view* v) {
   v->tiles_touched = off; off += ggd_align((size_t)P * sizeof(uint32_t));
   v->point_offsets = off; off += ggd_align((size_t)P * sizeof(uint32_t));
   v->clamped = off; off += ggd_align((size_t)P);
+  v->depth_keys = off; off += ggd_align((size_t)P * sizeof(uint32_t));
+  v->header = off; off += (P > 0 ? 256 : 0);
   v->total = off;
   return GGD_OK;
 }
@@ -99,6 +101,7 @@ extern "C" ggd_ctx* ggd_create(int device) {
   if (!ctx) { ggd_fail(nullptr, GGD_E_NOMEM, "out of host memory"); return nullptr; }
   ctx->device = device;
   if (const char* e = getenv("GGD_EXP_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->opt[GGD_OPT_EXP_MODE] = v; }
+  if (const char* e = getenv("GGD_BINNING")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->opt[GGD_OPT_BINNING] = v; }
   if (const char* e = getenv("GGD_BLEND_CULL")) ctx->opt[GGD_OPT_BLEND_CULL] = atoi(e) != 0;
   int prev = 0;
   (void)hipGetDevice(&prev);
@@ -132,7 +135,7 @@ extern "C" const char* ggd_last_error(ggd_ctx* ctx) { return ctx ? ctx->err.c_st
 
 extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
   if (!ctx) return GGD_E_INVALID;
-  static const int kMax[GGD_OPT_COUNT] = {2, 1};
+  static const int kMax[GGD_OPT_COUNT] = {2, 1, 2};
   if (option < 0 || option >= GGD_OPT_COUNT || value < 0 || value > kMax[option])
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_set_option: unknown option or value");
   ctx->opt[option] = value;
@@ -213,15 +216,19 @@ extern "C" int ggd_forward_geometry(ggd_ctx* ctx, void* stream, const ggd_params
   uint32_t* tiles = reinterpret_cast<uint32_t*>(gb + gv.tiles_touched);
   uint32_t* offsets = reinterpret_cast<uint32_t*>(gb + gv.point_offsets);
   uint8_t* clamped = reinterpret_cast<uint8_t*>(gb + gv.clamped);
+  uint32_t* depth_keys = reinterpret_cast<uint32_t*>(gb + gv.depth_keys);
+  uint32_t* header = reinterpret_cast<uint32_t*>(gb + gv.header);
 
   const size_t scan_tmp = ggd_scan_tmp_bytes(prm->P);
   rc = ggd_reserve_scratch(ctx, scan_tmp, s);
   if (rc != GGD_OK) return rc;
   if (prm->prefiltered) GGD_HIP(hipMemsetAsync(ctx->d_words + 1, 0, sizeof(uint32_t), s));
+  GGD_HIP(hipMemsetAsync(header, 0, 256, s));
   {
     StageTimer t(ctx, ST_PREPROCESS, s);
     rc = ggd_launch_preprocess(ctx, s, *prm, means3D, shs, colors_precomp, opacities, scales, rotations,
-                               cov3D_precomp, splat, tiles, shs ? clamped : nullptr, radii, ctx->d_words + 1);
+                               cov3D_precomp, splat, tiles, shs ? clamped : nullptr, radii, depth_keys, header,
+                               ctx->d_words + 1);
     if (rc != GGD_OK) return rc;
   }
   {
@@ -266,6 +273,36 @@ extern "C" int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* 
   const int T = ((prm->width + 15) / 16) * ((prm->height + 15) / 16);
   const int nbits = ggd_sort_bits(prm->width, prm->height);
 
+  const int bmode = ctx->opt[GGD_OPT_BINNING];
+  const bool tilebin = (bmode == 2 || (bmode == 1 && R >= (1 << 20))) && !prm->debug && ggd_tilebin_supported(T);
+  if (R > 0 && tilebin) {
+    // depth-sort the Gaussians once (32-bit keys), then one stable tile-binning pass
+    const uint32_t* depth_keys = reinterpret_cast<const uint32_t*>(gb + gv.depth_keys);
+    const size_t pairs = ggd_align((size_t)prm->P * sizeof(uint32_t));
+    const size_t sort_tmp = ggd_sort32_tmp_bytes(prm->P);
+    const size_t bin_tmp = ggd_tilebin_tmp_bytes(prm->P, T);
+    rc = ggd_reserve_scratch(ctx, 4 * pairs + sort_tmp + bin_tmp, s);
+    if (rc != GGD_OK) return rc;
+    char* sc = static_cast<char*>(ctx->scratch);
+    uint32_t* ka = reinterpret_cast<uint32_t*>(sc);
+    uint32_t* va = reinterpret_cast<uint32_t*>(sc + pairs);
+    uint32_t* kb = reinterpret_cast<uint32_t*>(sc + 2 * pairs);
+    uint32_t* vb = reinterpret_cast<uint32_t*>(sc + 3 * pairs);
+    void* tmp = sc + 4 * pairs;
+    void* bin_tmp_ptr = sc + 4 * pairs + sort_tmp;  // the sort's histogram block stays alive for the binning pass
+    {
+      StageTimer t(ctx, ST_SORT, s);
+      rc = ggd_launch_sort32_iota(ctx, s, depth_keys, ka, va, kb, vb, prm->P, 32, tmp, sort_tmp);
+      if (rc != GGD_OK) return rc;
+    }
+    {
+      StageTimer t(ctx, ST_DUPLICATE, s);
+      // culled Gaussians carry the key 0xFFFFFFFF: their count is bin 255 of the top-digit histogram of the depth sort
+      const uint32_t* culled = static_cast<const uint32_t*>(tmp) + 3 * 256 + 255;
+      rc = ggd_launch_tilebin(ctx, s, *prm, splat, tiles, va, culled, list, ranges, bin_tmp_ptr, bin_tmp);
+      if (rc != GGD_OK) return rc;
+    }
+  } else {
   if (R > 0) {
     const size_t sort_tmp = ggd_sort_tmp_bytes(R);
     rc = ggd_reserve_scratch(ctx, sort_tmp, s);
@@ -300,6 +337,7 @@ extern "C" int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* 
     StageTimer t(ctx, ST_RANGES, s);
     rc = ggd_launch_ranges(ctx, s, keys, R, ranges, T);
     if (rc != GGD_OK) return rc;
+  }
   }
   {
     StageTimer t(ctx, ST_BLEND, s);

@@ -29,7 +29,7 @@ struct ggd_ctx {
   void* dbg_keys = nullptr;     // debug copy of the unsorted list
   void* dbg_vals = nullptr;
   size_t dbg_cap = 0;
-  int opt[GGD_OPT_COUNT] = {0, 1};
+  int opt[GGD_OPT_COUNT] = {0, 1, 1};
   bool profiling = false;
   hipEvent_t ev[2 * ST_COUNT] = {};
   bool ev_used[ST_COUNT] = {};
@@ -63,7 +63,7 @@ int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, co
                           const float* shs, const float* colors_precomp, const float* opacities,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           ggd_splat* splat, uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii,
-                          uint32_t* trap_flag);
+                          uint32_t* depth_keys, uint32_t* visible_count, uint32_t* trap_flag);
 int ggd_launch_mark_visible(ggd_ctx* ctx, hipStream_t s, int P, const float* means3D, const float* view,
                             uint8_t* present);
 // inclusive scan of a uint32 array; total written to *d_total (device)
@@ -73,11 +73,22 @@ size_t ggd_scan_tmp_bytes(int64_t n);
 int ggd_launch_duplicate(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
                          const uint32_t* tiles_touched, const uint32_t* offsets, uint64_t* keys, uint32_t* vals);
 size_t ggd_sort_tmp_bytes(int64_t n);
+size_t ggd_sort32_tmp_bytes(int64_t n);
 // stable LSD radix sort of (key,val) pairs on key bits [0,nbits); result ends in (keys_a, vals_a); the input must
 // have been placed in the buffer ggd_sort_input_is_alt(nbits) says.
 int ggd_sort_input_is_alt(int nbits);
 int ggd_launch_sort(ggd_ctx* ctx, hipStream_t s, uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b,
                     uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes);
+// 32-bit-key variant (depth sort of the Gaussians).  keys_src is only read; the result ends in (keys_a, vals_a);
+// values start as the identity permutation.  nbits must be a multiple of 16 (even number of passes).
+int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
+                           uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes);
+// Tile binning (GGD_OPT_BINNING = 1): sorted Gaussian order -> per-tile lists + ranges.
+bool ggd_tilebin_supported(int T);
+size_t ggd_tilebin_tmp_bytes(int P, int T);
+int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
+                       const uint32_t* tiles_touched, const uint32_t* order, const uint32_t* culled_count,
+                       uint32_t* list, uint32_t* ranges, void* tmp, size_t tmp_bytes);
 int ggd_launch_ranges(ggd_ctx* ctx, hipStream_t s, const uint64_t* keys, int64_t n, uint32_t* ranges, int T);
 int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
                      const uint32_t* list, const uint32_t* ranges, float* out_color, float* final_T,

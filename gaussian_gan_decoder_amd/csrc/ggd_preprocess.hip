@@ -18,7 +18,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, ggd_splat* __restrict__ splat, uint32_t* __restrict__ tiles_touched,
-    uint8_t* __restrict__ clamped, int32_t* __restrict__ radii, uint32_t* __restrict__ trap_flag) {
+    uint8_t* __restrict__ clamped, int32_t* __restrict__ radii, uint32_t* __restrict__ depth_keys,
+    uint32_t* __restrict__ visible_count, uint32_t* __restrict__ trap_flag) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   const Mat16 V = load_mat(view);
@@ -98,6 +99,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 
   radii[i] = irad;
   tiles_touched[i] = ntiles;
+  depth_keys[i] = visible ? __float_as_uint(t[2]) : 0xFFFFFFFFu;
+  (void)visible_count;
   if (clamped) clamped[i] = (uint8_t)clamp_bits;
   if (visible) {
     float4* dst = reinterpret_cast<float4*>(splat + i);
@@ -122,13 +125,13 @@ int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, co
                           const float* shs, const float* colors_precomp, const float* opacities,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           ggd_splat* splat, uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii,
-                          uint32_t* trap_flag) {
+                          uint32_t* depth_keys, uint32_t* visible_count, uint32_t* trap_flag) {
   if (prm.P == 0) return GGD_OK;
   const int grid = (prm.P + 255) / 256;
   hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, s, prm.P, prm.M, prm.sh_degree, prm.width,
                      prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.viewmatrix,
                      prm.projmatrix, prm.campos, means3D, shs, colors_precomp, opacities, scales, rotations,
-                     cov3D_precomp, splat, tiles_touched, clamped, radii, trap_flag);
+                     cov3D_precomp, splat, tiles_touched, clamped, radii, depth_keys, visible_count, trap_flag);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }

@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-GGD_EXP_MODE=0 python -m pytest tests/test_raster_backward_gpu.py -m gpu -q -s > gpurun_out/bwd0.log 2>&1
-GGD_EXP_MODE=1 python -m pytest tests/test_raster_backward_gpu.py -m gpu -q -s > gpurun_out/bwd1.log 2>&1
-tail -3 gpurun_out/bwd0.log gpurun_out/bwd1.log
+timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -3
+for w in 1M_1024_cube 1M_1024_shell 100k_512_cube; do for b in 0 1; do echo "$w BINNING=$b"; GGD_BINNING=$b timeout 200 python bench.py --workload $w --steps 100 --warmup 10 --no-cpu-baseline --no-train | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), 'fps', d['ms_per_step'], d['stage_ms'])"; done; done

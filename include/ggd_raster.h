@@ -81,6 +81,8 @@ typedef struct ggd_geom_view {
   size_t tiles_touched; /* uint32[P] */
   size_t point_offsets; /* uint32[P], inclusive prefix sum of tiles_touched */
   size_t clamped;       /* uint8[P], bit c set <=> colour channel c was clamped at 0 */
+  size_t depth_keys;    /* uint32[P]: raw fp32 bits of the view-space depth, 0xFFFFFFFF for culled Gaussians */
+  size_t header;        /* uint32[64]: reserved (zeroed) */
   size_t total;
 } ggd_geom_view;
 
@@ -166,6 +168,11 @@ enum {
   GGD_OPT_EXP_MODE = 0,   /* blend exp(): 0 = ocml expf (<=1 ulp, default), 1 = native 2^(x*log2e) (fast, ~3 ulp),
                              2 = compensated 2^x (v_exp_f32 + product-residual correction, ~1 ulp) */
   GGD_OPT_BLEND_CULL = 1, /* 1 (default) = skip records whose alpha cannot reach 1/255 anywhere in the tile */
+  GGD_OPT_BINNING = 2,    /* how the per-tile sorted lists are built (results are identical):
+                             0 = duplicateWithKeys + 64-bit (tile|depth) radix sort + identifyTileRanges,
+                             2 = depth-sort the Gaussians once, then ONE stable tile-binning pass,
+                             1 (default) = auto: 2 when num_rendered >= 2^20 (where it is faster), else 0.
+                             debug=1 (key taps) or a tile grid beyond the LDS budget always uses 0 */
   GGD_OPT_COUNT
 };
 int ggd_set_option(ggd_ctx* ctx, int option, int value);

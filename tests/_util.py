@@ -50,10 +50,12 @@ def run_oracle(d, dtype=np.float32, stop_after=None):
                      scale_modifier=d["scale_modifier"], dtype=dtype, stop_after=stop_after)
 
 
-def run_native(d, device="cuda:0", debug=True):
-    """Forward through the C ABI (via the _C-style wrapper); returns dict with torch outputs + decoded buffers."""
+def run_native(d, device="cuda:0", debug=True, binning=None):
+    """Forward through the C ABI (via the _C-style wrapper); returns dict with torch outputs + decoded buffers.
+    binning: None = library default (auto), 0 = radix-sort path, 2 = force the tile-binning path."""
     from gaussian_gan_decoder_amd import rasterizer as R, _capi
     dev = torch.device(device)
+    _capi.context_for(dev).set_option(_capi.OPT_BINNING, 1 if binning is None else binning)
     t = lambda x: torch.empty(0, device=dev) if x is None else x.to(dev)
     num_rendered, color, radii, geom, binning, img = R.rasterize_gaussians_native(
         t(d["bg"]), t(d["means3D"]), t(d["colors_precomp"]), t(d["opacities"]), t(d["scales"]), t(d["rotations"]),

@@ -70,6 +70,14 @@ def test_forward_stages_match_oracle(native_lib, case):
     assert flips <= max(1, (d["W"] * d["H"]) // 100000), f"{flips} n_contrib mismatches"
     assert err[:, same].max(initial=0.0) <= RGB_ATOL, f"max |dRGB| = {err[:, same].max()}"
     assert np.abs(n["final_T"] - o["final_T"])[same].max(initial=0.0) <= RGB_ATOL
+    # ---- the production binning path (depth-sort the Gaussians + one stable tile-binning pass; debug=0) must build
+    #      the very same lists / ranges as the duplicateWithKeys + radix-sort path used above (debug=1 key taps)
+    n2 = run_native(d, debug=False, binning=2)
+    assert n2["num_rendered"] == o["num_rendered"]
+    np.testing.assert_array_equal(n2["ranges"], o["ranges"])
+    np.testing.assert_array_equal(n2["point_list"], o["point_list"])
+    np.testing.assert_array_equal(n2["n_contrib"], n["n_contrib"])
+    np.testing.assert_array_equal(n2["color"].cpu().numpy(), color)
 
 
 def test_empty_and_all_culled(native_lib):
