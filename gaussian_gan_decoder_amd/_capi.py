@@ -17,7 +17,7 @@ EXPORTS = [
     "ggd_geom_bytes", "ggd_binning_bytes", "ggd_img_bytes", "ggd_geom_layout", "ggd_binning_layout",
     "ggd_img_layout", "ggd_sort_bits", "ggd_create", "ggd_destroy", "ggd_last_error", "ggd_version",
     "ggd_forward_geometry", "ggd_forward_render", "ggd_backward", "ggd_mark_visible", "ggd_debug_unsorted",
-    "ggd_set_option", "ggd_get_option", "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
+    "ggd_triplane_forward", "ggd_triplane_backward", "ggd_set_option", "ggd_get_option", "ggd_blend_stats", "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
 ]
 
 
@@ -41,7 +41,7 @@ class ImgView(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("ranges", "final_T", "n_contrib", "total")]
 
 
-OPT_EXP_MODE, OPT_BLEND_CULL, OPT_BINNING = 0, 1, 2
+OPT_EXP_MODE, OPT_BLEND_CULL, OPT_BINNING, OPT_BLEND_SPLIT = 0, 1, 2, 3
 SPLAT_BYTES = 48
 SPLAT_FIELDS = ("x", "y", "conA", "conB", "conC", "opacity", "r", "g", "b", "depth", "radius", "tiles_touched")
 
@@ -78,8 +78,11 @@ def load():
         lib.ggd_backward.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 6 + [vp, vp, vp, vp, i64, vp] + [vp] * 8
         lib.ggd_mark_visible.argtypes = [vp, vp, i32, vp, vp, vp, vp]
         lib.ggd_debug_unsorted.argtypes = [vp, vp, vp, vp, i64]
+        lib.ggd_triplane_forward.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, C.c_float, vp]
+        lib.ggd_triplane_backward.argtypes = [vp, vp, i32, i32, i32, vp, i32, C.c_float, vp, vp]
         lib.ggd_set_option.argtypes = [vp, C.c_int, C.c_int]
         lib.ggd_get_option.argtypes = [vp, C.c_int]
+        lib.ggd_blend_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_ulonglong)]
         lib.ggd_set_profiling.argtypes = [vp, C.c_int]
         lib.ggd_stage_name.restype = C.c_char_p; lib.ggd_stage_name.argtypes = [C.c_int]
         lib.ggd_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
@@ -107,6 +110,12 @@ class Context:
 
     def set_option(self, option: int, value: int):
         self.check(self.lib.ggd_set_option(self.handle, int(option), int(value)))
+
+    def blend_stats(self, enable: bool):
+        """Start/stop the forward-blend work counters; returns the counters gathered since the last start."""
+        out = (C.c_ulonglong * 5)()
+        self.check(self.lib.ggd_blend_stats(self.handle, int(bool(enable)), out))
+        return dict(zip(("visited", "culled", "lanes", "pixels", "listed"), [int(v) for v in out]))
 
     def set_profiling(self, on: bool):
         self.check(self.lib.ggd_set_profiling(self.handle, int(bool(on))))

@@ -54,39 +54,64 @@ __device__ __forceinline__ float blend_exp(float x) {
   return expf(x);                   // ocml, <= 1 ulp
 }
 
-// One wave = one 16x16 tile, 4 horizontally adjacent pixels per lane.  Per staged record:
-//   (1) the four `power` values with packed fp32 math (operation order == the algorithm's published form),
-//   (2) CULL: if no pixel of the tile can reach alpha >= 1/255 -- tested in the power domain against a per-record
+// Wave <-> pixel mapping of the blend kernels.  PXL = pixels per lane (horizontally adjacent):
+//   PXL = 4: one wave per 16x16 tile (lane = 4x1 pixels, 4 lanes per row, 16 rows);
+//   PXL = 2: two waves per tile, each a 16x8 half (lane = 2x1 pixels, 8 lanes per row, 8 rows) -- finer culling and
+//            earlier "all pixels done" exits, twice the waves (better latency hiding on small images).
+// The halves of one tile are T blocks apart so that both land on the same XCD (block b -> XCD b % 8) and share L2.
+template <int PXL>
+struct WaveGeom {
+  int px0, py;
+  uint32_t lo, hi;
+  __device__ __forceinline__ WaveGeom(int gx, int T, const uint32_t* __restrict__ ranges) {
+    constexpr int LPR = 16 / PXL, ROWS = 64 / LPR;
+    const int tile = (int)blockIdx.x % T, sub = (int)blockIdx.x / T;
+    const int tx = tile % gx, ty = tile / gx;
+    const int lane = threadIdx.x;
+    px0 = tx * 16 + (lane % LPR) * PXL;
+    py = ty * 16 + sub * ROWS + lane / LPR;
+    const uint2 r = reinterpret_cast<const uint2*>(ranges)[tile];
+    lo = r.x; hi = r.y;
+  }
+};
+
+// Forward blend.  Per staged record:
+//   (1) the `power` values of the lane's pixels with packed fp32 math (operation order == the published form),
+//   (2) CULL: if no pixel of the wave can reach alpha >= 1/255 -- tested in the power domain against a per-record
 //       threshold ln(1/(255*opacity)) lowered by a safety margin, so the decision is exact w.r.t. the float alpha
 //       test that follows -- the whole wave skips the record with one ballot, before any exp,
 //   (3) the exact per-pixel tests and the blend update.
 // A finished pixel gets x = +inf: its power becomes -inf/NaN and it drops out in (2) with no extra instructions.
-template <int EXP_MODE, bool CULL>
-__global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx, const ggd_splat* __restrict__ splat,
+template <int EXP_MODE, bool CULL, int PXL>
+__global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx, int T,
+                                                           const ggd_splat* __restrict__ splat,
                                                            const uint32_t* __restrict__ list,
                                                            const uint32_t* __restrict__ ranges,
                                                            const float* __restrict__ bg,
                                                            float* __restrict__ out_color,
                                                            float* __restrict__ final_T,
-                                                           uint32_t* __restrict__ n_contrib) {
+                                                           uint32_t* __restrict__ n_contrib,
+                                                           unsigned long long* __restrict__ stats) {
+  constexpr int NP = PXL / 2;  // pixel pairs per lane
   __shared__ float4 s_rec[64 * 3];
   const int lane = threadIdx.x;
-  const TileGeom g = tile_geom(gx, ranges);
+  const WaveGeom<PXL> g(gx, T, ranges);
   const bool row_in = g.py < H;
   const float INF = __builtin_huge_valf();
-  float T[4], C[4][3];
-  uint32_t last[4];
-  f2 pxA, pxB;  // pixel x coordinates (0,1) and (2,3); +inf once the pixel is finished / outside the image
+  uint32_t st_visited = 0, st_culled = 0, st_lanes = 0, st_pixels = 0;  // wave-uniform debug counters (GGD stats)
+  float Tr[PXL], C[PXL][3];
+  uint32_t last[PXL];
+  f2 px[NP];  // pixel x coordinates; +inf once the pixel is finished / outside the image
   int alive = 0;
   const float pyf = (float)g.py;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    T[k] = 1.0f; C[k][0] = C[k][1] = C[k][2] = 0.0f;
+  for (int k = 0; k < PXL; ++k) {
+    Tr[k] = 1.0f; C[k][0] = C[k][1] = C[k][2] = 0.0f;
     last[k] = 0;
     const bool in = row_in && (g.px0 + k) < W;
     alive += in ? 1 : 0;
     const float x = in ? (float)(g.px0 + k) : INF;
-    if (k == 0) pxA.x = x; else if (k == 1) pxA.y = x; else if (k == 2) pxB.x = x; else pxB.y = x;
+    if (k & 1) px[k >> 1].y = x; else px[k >> 1].x = x;
   }
 
   float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
@@ -116,66 +141,97 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
       const float dy = a.y - pyf;
       const float cdy2 = b.x * dy * dy;
       const f2 gxx = {a.x, a.x};
-      const f2 dxA = gxx - pxA, dxB = gxx - pxB;
-      const f2 powA = -0.5f * (a.z * dxA * dxA + cdy2) - a.w * dxA * dy;
-      const f2 powB = -0.5f * (a.z * dxB * dxB + cdy2) - a.w * dxB * dy;
-      const bool n0 = powA.x >= c.y, n1 = powA.y >= c.y, n2 = powB.x >= c.y, n3 = powB.y >= c.y;
-      if (__ballot(n0 || n1 || n2 || n3) == 0ull) continue;
-      const uint32_t contributor = cbase + (uint32_t)j + 1u;
-#define GGD_PIXEL(k, POWER, NEED, PX)                                                        \
-      {                                                                                      \
-        const float power = POWER;                                                           \
-        const float alpha = fminf(0.99f, b.y * blend_exp<EXP_MODE>(power));                  \
-        const bool live = (NEED) && !(power > 0.0f) && !(alpha < ALPHA_FLOOR);               \
-        const float test_T = T[k] * (1.0f - alpha);                                          \
-        if (live) {                                                                          \
-          if (test_T < 0.0001f) {                                                            \
-            PX = INF;                                                                        \
-            alive -= 1;                                                                      \
-          } else {                                                                           \
-            C[k][0] += b.z * alpha * T[k];                                                   \
-            C[k][1] += b.w * alpha * T[k];                                                   \
-            C[k][2] += c.x * alpha * T[k];                                                   \
-            T[k] = test_T;                                                                   \
-            last[k] = contributor;                                                           \
-          }                                                                                  \
-        }                                                                                    \
+      f2 pw[NP];
+      bool need[PXL];
+      bool lane_need = false;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const f2 dx = gxx - px[p];
+        pw[p] = -0.5f * (a.z * dx * dx + cdy2) - a.w * dx * dy;
+        need[2 * p] = pw[p].x >= c.y; need[2 * p + 1] = pw[p].y >= c.y;
+        lane_need = lane_need || need[2 * p] || need[2 * p + 1];
       }
-      GGD_PIXEL(0, powA.x, n0, pxA.x)
-      GGD_PIXEL(1, powA.y, n1, pxA.y)
-      GGD_PIXEL(2, powB.x, n2, pxB.x)
-      GGD_PIXEL(3, powB.y, n3, pxB.y)
-#undef GGD_PIXEL
+      const uint64_t need_lanes = __ballot(lane_need);
+      st_visited += 1;
+      if (need_lanes == 0ull) { st_culled += 1; continue; }
+      if (stats) {
+        st_lanes += (uint32_t)__popcll(need_lanes);
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) st_pixels += (uint32_t)__popcll(__ballot(need[k]));
+      }
+      const uint32_t contributor = cbase + (uint32_t)j + 1u;
+#pragma unroll
+      for (int k = 0; k < PXL; ++k) {
+        // branch-free update (selects, no divergent control flow: the recurrence state stays in place)
+        const float power = (k & 1) ? pw[k >> 1].y : pw[k >> 1].x;
+        const float alpha = fminf(0.99f, b.y * blend_exp<EXP_MODE>(power));
+        const bool live = need[k] && !(power > 0.0f) && !(alpha < ALPHA_FLOOR);
+        const float test_T = Tr[k] * (1.0f - alpha);
+        const bool stop = live && (test_T < 0.0001f);
+        const bool upd = live && !(test_T < 0.0001f);
+        const float i0 = b.z * alpha * Tr[k], i1 = b.w * alpha * Tr[k], i2 = c.x * alpha * Tr[k];
+        C[k][0] += upd ? i0 : 0.0f;
+        C[k][1] += upd ? i1 : 0.0f;
+        C[k][2] += upd ? i2 : 0.0f;
+        Tr[k] = upd ? test_T : Tr[k];
+        last[k] = upd ? contributor : last[k];
+        if (k & 1) px[k >> 1].y = stop ? INF : px[k >> 1].y; else px[k >> 1].x = stop ? INF : px[k >> 1].x;
+        alive -= stop ? 1 : 0;
+      }
     }
   }
 
+  if (stats && lane == 0) {
+    atomicAdd(stats + 0, (unsigned long long)st_visited);
+    atomicAdd(stats + 1, (unsigned long long)st_culled);
+    atomicAdd(stats + 2, (unsigned long long)st_lanes);
+    atomicAdd(stats + 3, (unsigned long long)st_pixels);
+    atomicAdd(stats + 4, (unsigned long long)(g.hi - g.lo));
+  }
   if (!row_in) return;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const size_t HW = (size_t)H * W;
   const size_t pix0 = (size_t)g.py * W + g.px0;
-  if (g.px0 + 3 < W && (W & 3) == 0) {
-    *reinterpret_cast<float4*>(final_T + pix0) = make_float4(T[0], T[1], T[2], T[3]);
-    *reinterpret_cast<uint4*>(n_contrib + pix0) = make_uint4(last[0], last[1], last[2], last[3]);
-    *reinterpret_cast<float4*>(out_color + pix0) =
-        make_float4(C[0][0] + T[0] * bg0, C[1][0] + T[1] * bg0, C[2][0] + T[2] * bg0, C[3][0] + T[3] * bg0);
-    *reinterpret_cast<float4*>(out_color + HW + pix0) =
-        make_float4(C[0][1] + T[0] * bg1, C[1][1] + T[1] * bg1, C[2][1] + T[2] * bg1, C[3][1] + T[3] * bg1);
-    *reinterpret_cast<float4*>(out_color + 2 * HW + pix0) =
-        make_float4(C[0][2] + T[0] * bg2, C[1][2] + T[1] * bg2, C[2][2] + T[2] * bg2, C[3][2] + T[3] * bg2);
+  if (g.px0 + PXL - 1 < W && (W & 3) == 0) {
+    if constexpr (PXL == 4) {
+      *reinterpret_cast<float4*>(final_T + pix0) = make_float4(Tr[0], Tr[1], Tr[2], Tr[3]);
+      *reinterpret_cast<uint4*>(n_contrib + pix0) = make_uint4(last[0], last[1], last[2], last[3]);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float bgc = ch == 0 ? bg0 : (ch == 1 ? bg1 : bg2);
+        *reinterpret_cast<float4*>(out_color + ch * HW + pix0) = make_float4(
+            C[0][ch] + Tr[0] * bgc, C[1][ch] + Tr[1] * bgc, C[2][ch] + Tr[2] * bgc, C[3][ch] + Tr[3] * bgc);
+      }
+    } else {
+      *reinterpret_cast<float2*>(final_T + pix0) = make_float2(Tr[0], Tr[1]);
+      *reinterpret_cast<uint2*>(n_contrib + pix0) = make_uint2(last[0], last[1]);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float bgc = ch == 0 ? bg0 : (ch == 1 ? bg1 : bg2);
+        *reinterpret_cast<float2*>(out_color + ch * HW + pix0) =
+            make_float2(C[0][ch] + Tr[0] * bgc, C[1][ch] + Tr[1] * bgc);
+      }
+    }
   } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < PXL; ++k) {
       if (g.px0 + k < W) {
-        final_T[pix0 + k] = T[k];
+        final_T[pix0 + k] = Tr[k];
         n_contrib[pix0 + k] = last[k];
-        out_color[pix0 + k] = C[k][0] + T[k] * bg0;
-        out_color[HW + pix0 + k] = C[k][1] + T[k] * bg1;
-        out_color[2 * HW + pix0 + k] = C[k][2] + T[k] * bg2;
+        out_color[pix0 + k] = C[k][0] + Tr[k] * bg0;
+        out_color[HW + pix0 + k] = C[k][1] + Tr[k] * bg1;
+        out_color[2 * HW + pix0 + k] = C[k][2] + Tr[k] * bg2;
       }
     }
   }
 }
 
+// Backward blend.  Same wave/tile mapping as the forward; records are visited back-to-front from the last position
+// any pixel of the tile contributed to.  The pixel body is SELECT-FREE and packed (two pixels per VALU issue):
+// a pixel that does not see the record (culled, beyond its n_contrib, alpha < 1/255) gets alpha = G = 0, which makes
+// every state update an exact no-op (T/(1-0) = T; the pending (last_alpha, last_color) pair is folded into the
+// running colour one record early and then applied with weight 0), so no per-pixel branches or selects on the
+// 8 words of recurrence state are needed.  1/(1-alpha) is one v_rcp + one Newton step, shared by both divisions.
 template <int EXP_MODE, bool CULL>
 __global__ __launch_bounds__(64) void blend_backward_kernel(
     int W, int H, int gx, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ list,
@@ -190,8 +246,9 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
   const size_t HW = (size_t)H * W;
   const size_t pix0 = (size_t)g.py * W + g.px0;
 
-  float T[4], Tfin[4], gpx[4][3], acc[4][3], lastc[4][3], last_alpha[4], bgdot[4];
-  const f2 pxA = {(float)g.px0, (float)(g.px0 + 1)}, pxB = {(float)(g.px0 + 2), (float)(g.px0 + 3)};
+  // per-pixel state, packed as pairs: [0] = pixels (0,1), [1] = pixels (2,3)
+  f2 T[2], nTfin[2], la[2], bgdot[2], acc[2][3], lastc[2][3], gpx[2][3];
+  const f2 px[2] = {{(float)g.px0, (float)(g.px0 + 1)}, {(float)(g.px0 + 2), (float)(g.px0 + 3)}};
   uint32_t lastn[4];
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const float pyf = (float)g.py;
@@ -199,17 +256,27 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const bool in = row_in && (g.px0 + k) < W;
-    Tfin[k] = in ? final_T[pix0 + k] : 0.0f;
-    T[k] = Tfin[k];
+    const float tf = in ? final_T[pix0 + k] : 0.0f;
     lastn[k] = in ? n_contrib[pix0 + k] : 0u;
     maxn = max(maxn, lastn[k]);
+    float gg[3];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      gpx[k][ch] = in ? dL_dpix[ch * HW + pix0 + k] : 0.0f;
-      acc[k][ch] = 0.0f; lastc[k][ch] = 0.0f;
+    for (int ch = 0; ch < 3; ++ch) gg[ch] = in ? dL_dpix[ch * HW + pix0 + k] : 0.0f;
+    const float bd = (bg0 * gg[0] + bg1 * gg[1]) + bg2 * gg[2];
+    const int p = k >> 1;
+    if (k & 1) {
+      T[p].y = tf; nTfin[p].y = -tf; bgdot[p].y = bd;
+      gpx[p][0].y = gg[0]; gpx[p][1].y = gg[1]; gpx[p][2].y = gg[2];
+    } else {
+      T[p].x = tf; nTfin[p].x = -tf; bgdot[p].x = bd;
+      gpx[p][0].x = gg[0]; gpx[p][1].x = gg[1]; gpx[p][2].x = gg[2];
     }
-    last_alpha[k] = 0.0f;
-    bgdot[k] = (bg0 * gpx[k][0] + bg1 * gpx[k][1]) + bg2 * gpx[k][2];
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    la[p] = (f2){0.0f, 0.0f};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) { acc[p][ch] = (f2){0.0f, 0.0f}; lastc[p][ch] = (f2){0.0f, 0.0f}; }
   }
   // wave-uniform number of list positions anyone in the tile contributed to
 #pragma unroll
@@ -236,64 +303,79 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
     uint64_t touched = 0;
     for (int j = n - 1; j >= 0; --j) {
       const uint32_t pos0 = (cstart - g.lo) + (uint32_t)j;  // 0-based position in the tile's list
-      const float4 a = s_rec[j * 3 + 0];
-      const float4 b = s_rec[j * 3 + 1];
-      const float2 c2 = *reinterpret_cast<const float2*>(&s_rec[j * 3 + 2]);  // b, power threshold
+      const float4 a = s_rec[j * 3 + 0];                                         // x, y, conA, conB
+      const float4 b = s_rec[j * 3 + 1];                                         // conC, opacity, r, g
+      const float2 c2 = *reinterpret_cast<const float2*>(&s_rec[j * 3 + 2]);     // b, power threshold
       const float col[3] = {b.z, b.w, c2.x};
       const float dy = a.y - pyf;
       const float cdy2 = b.x * dy * dy;
       const f2 gxx = {a.x, a.x};
-      const f2 dxA = gxx - pxA, dxB = gxx - pxB;
-      const f2 powA = -0.5f * (a.z * dxA * dxA + cdy2) - a.w * dxA * dy;
-      const f2 powB = -0.5f * (a.z * dxB * dxB + cdy2) - a.w * dxB * dy;
-      const float dxs[4] = {dxA.x, dxA.y, dxB.x, dxB.y};
-      const float pows[4] = {powA.x, powA.y, powB.x, powB.y};
-      bool need[4];
+      f2 dx[2], pw[2];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) need[k] = (pos0 < lastn[k]) && (pows[k] >= c2.y);
-      if (__ballot(need[0] || need[1] || need[2] || need[3]) == 0ull) continue;  // nobody in the tile saw it
-      float s_col[3] = {0.f, 0.f, 0.f}, s_op = 0.f, s_cA = 0.f, s_cB = 0.f, s_cC = 0.f, s_mx = 0.f, s_my = 0.f;
+      for (int p = 0; p < 2; ++p) {
+        dx[p] = gxx - px[p];
+        pw[p] = -0.5f * (a.z * dx[p] * dx[p] + cdy2) - a.w * dx[p] * dy;
+      }
+      const bool n0 = (pos0 < lastn[0]) && (pw[0].x >= c2.y), n1 = (pos0 < lastn[1]) && (pw[0].y >= c2.y),
+                 n2 = (pos0 < lastn[2]) && (pw[1].x >= c2.y), n3 = (pos0 < lastn[3]) && (pw[1].y >= c2.y);
+      if (__ballot(n0 || n1 || n2 || n3) == 0ull) continue;  // nobody in the tile saw this Gaussian
+      const bool need[4] = {n0, n1, n2, n3};
+      f2 sc[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, sop = {0.f, 0.f}, scA = {0.f, 0.f}, scB = {0.f, 0.f},
+         scC = {0.f, 0.f}, smx = {0.f, 0.f}, smy = {0.f, 0.f};
       bool any = false;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float dx = dxs[k];
-        const float power = pows[k];
-        const float G = blend_exp<EXP_MODE>(power);
-        const float alpha = fminf(0.99f, b.y * G);
-        const bool live = need[k] && !(power > 0.0f) && !(alpha < ALPHA_FLOOR);
-        if (live) {
-          any = true;
-          T[k] = T[k] / (1.0f - alpha);
-          const float dchannel_dcolor = alpha * T[k];
-          float dL_dalpha = 0.0f;
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            acc[k][ch] = last_alpha[k] * lastc[k][ch] + (1.0f - last_alpha[k]) * acc[k][ch];
-            lastc[k][ch] = col[ch];
-            dL_dalpha += (col[ch] - acc[k][ch]) * gpx[k][ch];
-            s_col[ch] += dchannel_dcolor * gpx[k][ch];
-          }
-          dL_dalpha *= T[k];
-          last_alpha[k] = alpha;
-          dL_dalpha += (-Tfin[k] / (1.0f - alpha)) * bgdot[k];
-          const float dL_dG = b.y * dL_dalpha;
-          const float gdx = G * dx, gdy = G * dy;
-          const float dG_ddelx = -gdx * a.z - gdy * a.w;
-          const float dG_ddely = -gdy * b.x - gdx * a.w;
-          s_mx += dL_dG * dG_ddelx * ddelx_dx;
-          s_my += dL_dG * dG_ddely * ddely_dy;
-          s_cA += -0.5f * gdx * dx * dL_dG;
-          s_cB += -0.5f * gdx * dy * dL_dG;
-          s_cC += -0.5f * gdy * dy * dL_dG;
-          s_op += G * dL_dalpha;
+      for (int p = 0; p < 2; ++p) {
+        // exact per-pixel visibility test, then alpha = G = 0 for pixels that do not see the record
+        f2 G, alpha;
+        {
+          const float g0 = blend_exp<EXP_MODE>(pw[p].x), g1 = blend_exp<EXP_MODE>(pw[p].y);
+          const float a0 = fminf(0.99f, b.y * g0), a1 = fminf(0.99f, b.y * g1);
+          const bool l0 = need[2 * p] && !(pw[p].x > 0.0f) && !(a0 < ALPHA_FLOOR);
+          const bool l1 = need[2 * p + 1] && !(pw[p].y > 0.0f) && !(a1 < ALPHA_FLOOR);
+          any = any || l0 || l1;
+          G = (f2){l0 ? g0 : 0.0f, l1 ? g1 : 0.0f};
+          alpha = (f2){l0 ? a0 : 0.0f, l1 ? a1 : 0.0f};
         }
+        const f2 om = 1.0f - alpha;
+        f2 inv;
+        {
+          float i0 = __builtin_amdgcn_rcpf(om.x), i1 = __builtin_amdgcn_rcpf(om.y);
+          i0 = __builtin_fmaf(i0, __builtin_fmaf(-om.x, i0, 1.0f), i0);
+          i1 = __builtin_fmaf(i1, __builtin_fmaf(-om.y, i1, 1.0f), i1);
+          inv = (f2){i0, i1};
+        }
+        T[p] = T[p] * inv;
+        const f2 dchannel_dcolor = alpha * T[p];
+        const f2 oml = 1.0f - la[p];
+        f2 dL_dalpha = {0.0f, 0.0f};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          acc[p][ch] = la[p] * lastc[p][ch] + oml * acc[p][ch];
+          lastc[p][ch] = (f2){col[ch], col[ch]};
+          dL_dalpha += (col[ch] - acc[p][ch]) * gpx[p][ch];
+          sc[ch] += dchannel_dcolor * gpx[p][ch];
+        }
+        dL_dalpha *= T[p];
+        la[p] = alpha;
+        dL_dalpha += (nTfin[p] * inv) * bgdot[p];
+        const f2 dL_dG = b.y * dL_dalpha;
+        const f2 gdx = G * dx[p], gdy = G * dy;
+        const f2 dG_ddelx = -gdx * a.z - gdy * a.w;
+        const f2 dG_ddely = -gdy * b.x - gdx * a.w;
+        smx += dL_dG * dG_ddelx * ddelx_dx;
+        smy += dL_dG * dG_ddely * ddely_dy;
+        scA += -0.5f * gdx * dx[p] * dL_dG;
+        scB += -0.5f * gdx * dy * dL_dG;
+        scC += -0.5f * gdy * dy * dL_dG;
+        sop += G * dL_dalpha;
       }
       if (__ballot(any) != 0ull) {  // wave-uniform: somebody in the tile saw this Gaussian
         touched |= 1ull << j;
-        const float t0 = ggd_wave_sum_to63(s_col[0]), t1 = ggd_wave_sum_to63(s_col[1]),
-                    t2 = ggd_wave_sum_to63(s_col[2]), t3 = ggd_wave_sum_to63(s_op),
-                    t4 = ggd_wave_sum_to63(s_cA), t5 = ggd_wave_sum_to63(s_cB), t6 = ggd_wave_sum_to63(s_cC),
-                    t7 = ggd_wave_sum_to63(s_mx), t8 = ggd_wave_sum_to63(s_my);
+        const float t0 = ggd_wave_sum_to63(sc[0].x + sc[0].y), t1 = ggd_wave_sum_to63(sc[1].x + sc[1].y),
+                    t2 = ggd_wave_sum_to63(sc[2].x + sc[2].y), t3 = ggd_wave_sum_to63(sop.x + sop.y),
+                    t4 = ggd_wave_sum_to63(scA.x + scA.y), t5 = ggd_wave_sum_to63(scB.x + scB.y),
+                    t6 = ggd_wave_sum_to63(scC.x + scC.y), t7 = ggd_wave_sum_to63(smx.x + smx.y),
+                    t8 = ggd_wave_sum_to63(smy.x + smy.y);
         if (lane == 63) {
           float* o = s_sum + j * 9;
           o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = t5; o[6] = t6; o[7] = t7; o[8] = t8;
@@ -327,9 +409,18 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
   if (gx * gy == 0) return GGD_OK;
   const int em = ctx->opt[GGD_OPT_EXP_MODE];
   const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
-#define GGD_LAUNCH_FWD(EM, CU)                                                                                   \
-  hipLaunchKernelGGL((blend_forward_kernel<EM, CU>), dim3(gx * gy), dim3(64), 0, s, prm.width, prm.height, gx,  \
-                     splat, list, ranges, prm.bg, out_color, final_T, n_contrib)
+  const int T = gx * gy;
+  const int split = ctx->opt[GGD_OPT_BLEND_SPLIT];
+  const bool two = split == 2 || (split == 1 && true);  // auto: two half-tile waves per tile
+#define GGD_LAUNCH_FWD(EM, CU)                                                                                      \
+  do {                                                                                                              \
+    if (two)                                                                                                        \
+      hipLaunchKernelGGL((blend_forward_kernel<EM, CU, 2>), dim3(2 * T), dim3(64), 0, s, prm.width, prm.height, gx, \
+                         T, splat, list, ranges, prm.bg, out_color, final_T, n_contrib, ctx->blend_stats);         \
+    else                                                                                                            \
+      hipLaunchKernelGGL((blend_forward_kernel<EM, CU, 4>), dim3(T), dim3(64), 0, s, prm.width, prm.height, gx, T,  \
+                         splat, list, ranges, prm.bg, out_color, final_T, n_contrib, ctx->blend_stats);            \
+  } while (0)
   if (cull) {
     if (em == 0) GGD_LAUNCH_FWD(0, true); else if (em == 1) GGD_LAUNCH_FWD(1, true); else GGD_LAUNCH_FWD(2, true);
   } else {

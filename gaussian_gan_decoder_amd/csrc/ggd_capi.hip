@@ -102,13 +102,14 @@ extern "C" ggd_ctx* ggd_create(int device) {
   ctx->device = device;
   if (const char* e = getenv("GGD_EXP_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->opt[GGD_OPT_EXP_MODE] = v; }
   if (const char* e = getenv("GGD_BINNING")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->opt[GGD_OPT_BINNING] = v; }
+  if (const char* e = getenv("GGD_BLEND_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->opt[GGD_OPT_BLEND_SPLIT] = v; }
   if (const char* e = getenv("GGD_BLEND_CULL")) ctx->opt[GGD_OPT_BLEND_CULL] = atoi(e) != 0;
   int prev = 0;
   (void)hipGetDevice(&prev);
   bool ok = hipSetDevice(device) == hipSuccess &&
-            hipMalloc((void**)&ctx->d_words, 64) == hipSuccess &&
+            hipMalloc((void**)&ctx->d_words, 256) == hipSuccess &&
             hipHostMalloc((void**)&ctx->h_words, 64, hipHostMallocDefault) == hipSuccess &&
-            hipMemset(ctx->d_words, 0, 64) == hipSuccess;
+            hipMemset(ctx->d_words, 0, 256) == hipSuccess;
   for (int i = 0; ok && i < 2 * ST_COUNT; ++i) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
   (void)hipSetDevice(prev);
   if (!ok) {
@@ -135,12 +136,26 @@ extern "C" const char* ggd_last_error(ggd_ctx* ctx) { return ctx ? ctx->err.c_st
 
 extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
   if (!ctx) return GGD_E_INVALID;
-  static const int kMax[GGD_OPT_COUNT] = {2, 1, 2};
+  static const int kMax[GGD_OPT_COUNT] = {2, 1, 2, 2};
   if (option < 0 || option >= GGD_OPT_COUNT || value < 0 || value > kMax[option])
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_set_option: unknown option or value");
   ctx->opt[option] = value;
   return GGD_OK;
 }
+extern "C" int ggd_blend_stats(ggd_ctx* ctx, int enable, unsigned long long* out) {
+  if (!ctx) return GGD_E_INVALID;
+  unsigned long long* dev = reinterpret_cast<unsigned long long*>(ctx->d_words + 8);  // 5 x u64 inside the control block
+  GGD_HIP(hipDeviceSynchronize());
+  if (out && ctx->blend_stats) GGD_HIP(hipMemcpy(out, dev, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (enable) {
+    GGD_HIP(hipMemset(dev, 0, 5 * sizeof(unsigned long long)));
+    ctx->blend_stats = dev;
+  } else {
+    ctx->blend_stats = nullptr;
+  }
+  return GGD_OK;
+}
+
 extern "C" int ggd_get_option(ggd_ctx* ctx, int option) {
   if (!ctx || option < 0 || option >= GGD_OPT_COUNT) return GGD_E_INVALID;
   return ctx->opt[option];

@@ -29,7 +29,8 @@ struct ggd_ctx {
   void* dbg_keys = nullptr;     // debug copy of the unsorted list
   void* dbg_vals = nullptr;
   size_t dbg_cap = 0;
-  int opt[GGD_OPT_COUNT] = {0, 1, 1};
+  int opt[GGD_OPT_COUNT] = {0, 1, 1, 1};
+  unsigned long long* blend_stats = nullptr;  // debug: device counters filled by the forward blend when non-null
   bool profiling = false;
   hipEvent_t ev[2 * ST_COUNT] = {};
   bool ev_used[ST_COUNT] = {};

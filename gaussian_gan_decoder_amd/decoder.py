@@ -35,18 +35,105 @@ def sample_from_planes(plane_features: torch.Tensor, coordinates: torch.Tensor, 
     return out.permute(0, 3, 2, 1).reshape(n_planes, M, C)
 
 
+class _TriplaneMeanFn(torch.autograd.Function):
+    """mean over the 3 planes of sample_from_planes, through the HIP gather kernel (csrc/ggd_triplane.hip)."""
+
+    @staticmethod
+    def forward(ctx, plane_features, coordinates, box_warp):
+        import ctypes as C
+        from . import _capi
+        dev = plane_features.device
+        n_planes, Cc, H, W = plane_features.shape
+        planes_cl = plane_features.permute(0, 2, 3, 1).contiguous().float()
+        pos = coordinates.contiguous().float()
+        out = torch.empty((pos.shape[0], Cc), dtype=torch.float32, device=dev)
+        cx = _capi.context_for(dev)
+        with torch.cuda.device(dev):
+            cx.check(cx.lib.ggd_triplane_forward(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
+                                                 C.c_void_p(planes_cl.data_ptr()), Cc, H, W, C.c_void_p(pos.data_ptr()),
+                                                 pos.shape[0], float(box_warp), C.c_void_p(out.data_ptr())))
+        ctx.save_for_backward(pos)
+        ctx.meta = (Cc, H, W, float(box_warp))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes as C
+        from . import _capi
+        (pos,) = ctx.saved_tensors
+        Cc, H, W, box_warp = ctx.meta
+        dev = pos.device
+        dout = dout.contiguous().float()
+        dplanes_cl = torch.empty((3, H, W, Cc), dtype=torch.float32, device=dev)
+        cx = _capi.context_for(dev)
+        with torch.cuda.device(dev):
+            cx.check(cx.lib.ggd_triplane_backward(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), Cc, H, W,
+                                                  C.c_void_p(pos.data_ptr()), pos.shape[0], box_warp,
+                                                  C.c_void_p(dout.data_ptr()), C.c_void_p(dplanes_cl.data_ptr())))
+        return dplanes_cl.permute(0, 3, 1, 2), None, None
+
+
+def triplane_mean(plane_features: torch.Tensor, coordinates: torch.Tensor, box_warp: float = 1.0) -> torch.Tensor:
+    """== sample_from_planes(...).mean(0): [3, C, H, W], [M, 3] -> [M, C].  HIP gather kernel on the GPU (C a power of
+    two <= 64, 3 planes); the torch ops on the CPU (the decoder is host-side PyTorch per the north_star, so a CPU
+    path exists for tests -- unlike the rasterizer)."""
+    C = plane_features.shape[1]
+    if plane_features.is_cuda and plane_features.shape[0] == 3 and C <= 64 and (C & (C - 1)) == 0:
+        return _TriplaneMeanFn.apply(plane_features, coordinates, box_warp)
+    return sample_from_planes(plane_features, coordinates, box_warp).mean(0)
+
+
+class _TallLinearFn(torch.autograd.Function):
+    """y = x W^T + b for a TALL x ([N, in], N ~ 5e5).  Same forward as F.linear; the backward computes the weight
+    gradient dW = dy^T x as a batched split-K product (the N reduction cut into chunks -> torch.bmm -> sum) instead
+    of one [out, N] x [N, in] GEMM: on MI355X the single tall-skinny reduction GEMM is dispatched to a tile shape
+    that leaves most CUs idle (~1 ms per layer at N = 5e5, measured), the batched form keeps all of them busy."""
+    CHUNK = 2048
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        n = x.shape[0]
+        c = _TallLinearFn.CHUNK
+        main = (n // c) * c
+        dw = None
+        if main:
+            dw = torch.bmm(dy[:main].view(-1, c, dy.shape[1]).transpose(1, 2), x[:main].view(-1, c, x.shape[1])).sum(0)
+        if main < n:
+            tail = dy[main:].t() @ x[main:]
+            dw = tail if dw is None else dw + tail
+        return dx, dw, dy.sum(0)
+
+
+class TallLinear(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) with the split-K weight-gradient of _TallLinearFn."""
+
+    def forward(self, x):
+        if x.dim() == 2 and x.shape[0] >= 4 * _TallLinearFn.CHUNK and x.requires_grad | self.weight.requires_grad:
+            return _TallLinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 class Decoder(nn.Module):
     def __init__(self, n_features, out_features=3, hidden_dim=128):
         super().__init__()
         self.backbone = nn.Sequential(
-            nn.Linear(n_features, hidden_dim), nn.GELU(),
-            nn.Linear(hidden_dim, hidden_dim), nn.GELU(),
-            nn.Linear(hidden_dim, hidden_dim), nn.GELU(),
-            nn.Linear(hidden_dim, out_features))
+            TallLinear(n_features, hidden_dim), nn.GELU(),
+            TallLinear(hidden_dim, hidden_dim), nn.GELU(),
+            TallLinear(hidden_dim, hidden_dim), nn.GELU(),
+            TallLinear(hidden_dim, out_features))
 
     def forward(self, triplane_features, gaussian_features):
-        x = torch.concat([triplane_features.mean(0), gaussian_features], dim=-1)
-        return self.backbone(x)
+        # reference signature: triplane_features [3, N, C] (averaged here); a pre-averaged [N, C] is accepted too
+        feats = triplane_features.mean(0) if triplane_features.dim() == 3 else triplane_features
+        return self.backbone(torch.concat([feats, gaussian_features], dim=-1))
 
 
 class SequentialDecoderReverse(nn.Module):
@@ -67,7 +154,7 @@ class SequentialDecoderReverse(nn.Module):
         return -self.scale_activation(scale + 5) - 2.5
 
     def forward(self, feature_planes, init_position):
-        pf = sample_from_planes(feature_planes, init_position, self.box_warp)
+        pf = triplane_mean(feature_planes, init_position, self.box_warp)  # the 5 heads all average the planes
         info = init_position
         color = self.color_decoder(pf, info)
         info = torch.concat([info, color], dim=-1)

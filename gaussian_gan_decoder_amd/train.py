@@ -71,10 +71,12 @@ class DecoderTrainer:
         self.l1_weight, self.l2_weight = l1_weight, l2_weight
         torch.manual_seed(seed)
         self.decoder = SequentialDecoderReverse(plane_channels, hidden_dim).to(self.device)
-        # stand-in for the finetuned GAN backbone: one learnable tri-plane per scene ("latent")
+        # stand-in for the finetuned GAN backbone (shared, replicated, all-reduced like the reference's G): ONE learnable
+        # tri-plane, modulated per scene by a fixed per-scene channel code (the "latent" z of that scene)
         g = torch.Generator().manual_seed(seed + 17)
         self.planes = torch.nn.Parameter(
-            (0.5 * torch.randn(n_scenes_total, 3, plane_channels, plane_res, plane_res, generator=g)).to(self.device))
+            (0.5 * torch.randn(3, plane_channels, plane_res, plane_res, generator=g)).to(self.device))
+        self.latents = (1.0 + 0.25 * torch.randn(n_scenes_total, plane_channels, generator=g)).to(self.device)
         self.params = self.decoder.get_params_custom() + [self.planes]
         self.broadcast_parameters()
         self.optim = torch.optim.Adam([{"params": self.params, "lr": lr}])
@@ -119,7 +121,8 @@ class DecoderTrainer:
         total = 0.0
         B = batch.positions.shape[0]
         for b in range(B):
-            out = self.decoder(self.planes[int(batch.scene_id[b])], batch.positions[b])
+            planes = self.planes * self.latents[int(batch.scene_id[b])][None, :, None, None]
+            out = self.decoder(planes, batch.positions[b])
             gs = self.gaussians
             gs._xyz, gs._scaling, gs._rotation = out.xyz, out.scale, out.rotation
             gs._opacity, gs._features_dc = out.opacity, out.color.unsqueeze(1)

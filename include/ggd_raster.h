@@ -173,10 +173,28 @@ enum {
                              2 = depth-sort the Gaussians once, then ONE stable tile-binning pass,
                              1 (default) = auto: 2 when num_rendered >= 2^20 (where it is faster), else 0.
                              debug=1 (key taps) or a tile grid beyond the LDS budget always uses 0 */
+  GGD_OPT_BLEND_SPLIT = 3, /* forward blend: 0 = one wave per 16x16 tile (4 px/lane), 2 = two waves per tile (16x8
+                             halves, 2 px/lane), 1 (default) = auto */
   GGD_OPT_COUNT
 };
 int ggd_set_option(ggd_ctx* ctx, int option, int value);
+/* Debug: blend work counters of the NEXT forward calls: out[0]=records visited, [1]=records culled by the wave-level
+ * test, [2]=lanes with a candidate pixel (summed over visited records), [3]=candidate pixels, [4]=sum of list lengths.
+ * enable=1 starts (and zeroes) counting, enable=0 stops; out (host, 5 x uint64) may be NULL. */
+int ggd_blend_stats(ggd_ctx* ctx, int enable, unsigned long long* out);
 int ggd_get_option(ggd_ctx* ctx, int option);
+
+/*
+ * Tri-plane feature gather of the per-point decoder (input side of the raster path; replaces the three torch ops
+ * sample_from_planes -> grid_sample -> mean(0) of main/decoder_models/sequential_decoder_reverse.py:42-57 and
+ * base_decoder.py:22):  out[n,:] = mean over the 3 EG3D planes of the bilinear sample (zero padding,
+ * align_corners = False) at (2/box_warp) * pos[n].  planes_cl is CHANNEL-LAST [3][H][W][C], C a power of two <= 64.
+ * The backward zero-fills dplanes_cl [3][H][W][C] and scatter-adds dout[N,C]; positions receive no gradient.
+ */
+int ggd_triplane_forward(ggd_ctx* ctx, void* stream, const float* planes_cl, int32_t C, int32_t H, int32_t W,
+                         const float* pos, int32_t N, float box_warp, float* out);
+int ggd_triplane_backward(ggd_ctx* ctx, void* stream, int32_t C, int32_t H, int32_t W, const float* pos, int32_t N,
+                          float box_warp, const float* dout, float* dplanes_cl);
 
 /* Per-stage device time (ms, hipEvent pairs on `stream`) of the most recent forward_geometry / forward_render /
  * backward call when profiling is on.  Stage names: ggd_stage_name(i), i in [0, ggd_stage_count()). */
