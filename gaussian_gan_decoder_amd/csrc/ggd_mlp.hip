@@ -1,0 +1,247 @@
+// ggd_mlp.hip -- fused per-point Gaussian decoder (5 chained MLP heads) on the gfx950 matrix cores.
+//
+// SURVEY.md section 8f row 1 / BASELINE config 3: the only genuinely dense contraction next to the raster path.
+// Replaces, for inference, the 5 x `Decoder` calls of main/decoder_models/sequential_decoder_reverse.py:68-85
+// (each: concat -> Linear+GELU x3 -> Linear, main/decoder_models/base_decoder.py:8-27):
+//   color(3) -> opacity(1) -> rotation(4) -> scale(3, -softplus(s+5)-2.5) -> xyz(3, *0.01 + position),
+// every head seeing [plane_mean(32), position(3), outputs of the earlier heads].
+//
+// Formulation: TRANSPOSED GEMMs, Y^T[feature][point] = W[feature][k] . X^T[k][point], with
+// v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  The C/D layout of one layer (lane = point column, 4 consecutive
+// feature rows per lane group) IS a valid B-operand layout of the next layer, so activations never leave registers
+// between layers: no LDS round trip, no transposes.  (The MFMA pairs element e of lane (i,g) in A with element e
+// of lane (j,g) in B, so any assignment of k to (g,e) is legal as long as A and B agree; the weight rows are
+// pre-permuted on the host to the order the D layout produces.)  Weights of ONE head (<= 93 KiB bf16, rows padded by
+// 16 B so the 16-lane ds_read_b128 groups are bank-conflict free) are resident in LDS; a 512-thread workgroup
+// (8 waves: two per SIMD, one in its MFMA phase while the other does its GELUs) walks 32-point slabs.
+// GELU is the erf form with a transcendental-free polynomial erf (|GELU err| < 5.7e-5, far below bf16 resolution).
+#include "ggd_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int HID = 128;
+constexpr int NHEAD = 5;
+// LDS image of one head (bytes); rows are K bf16 + 8 bf16 of padding
+constexpr int ROW1 = (64 + 8) * 2;    // layer 1: K = 64 (32 plane features + 32 info slots)
+constexpr int ROW2 = (128 + 8) * 2;   // layers 2..4: K = 128
+constexpr int OFF_W1 = 0;
+constexpr int OFF_W2 = OFF_W1 + HID * ROW1;
+constexpr int OFF_W3 = OFF_W2 + HID * ROW2;
+constexpr int OFF_W4 = OFF_W3 + HID * ROW2;
+constexpr int OFF_B = OFF_W4 + 16 * ROW2;          // fp32 biases: b1[128] b2[128] b3[128] b4[16]
+constexpr int HEAD_BYTES = OFF_B + (3 * HID + 16) * 4;  // 94,784 B
+constexpr int MLP_THREADS = 512;
+constexpr int MLP_WAVES = MLP_THREADS / 64;
+constexpr int SLAB = 32;  // points per wave iteration (two 16-point MFMA column tiles share every weight read)
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+// Two GELUs per call, transcendental-free and packed (v_pk_fma_f32): 0.5 x (1 + erf(x / sqrt2)) with
+// erf(z) ~= z * P8(z^2) on [0, 3] (least-squares fit on Chebyshev nodes) clamped to 1 beyond; max |GELU error| 5.7e-5
+// over all x, two orders below bf16 resolution.  (The exact-erf Abramowitz-Stegun form costs a v_rcp and a v_exp per
+// value -- the kernel was VALU-bound on it: 14k of 17k cycles per slab.)
+__device__ __forceinline__ f2v gelu2(f2v x) {
+  // erf is odd: work on the signed argument, clamp with v_med3 (no abs / copysign instructions)
+  f2v z = x * 0.70710678118654752f;
+  z = (f2v){__builtin_amdgcn_fmed3f(z.x, -3.0f, 3.0f), __builtin_amdgcn_fmed3f(z.y, -3.0f, 3.0f)};
+  const f2v s2 = z * z;
+  f2v p = {4.0719861e-08f, 4.0719861e-08f};
+  p = __builtin_elementwise_fma(p, s2, (f2v){-1.9457509e-06f, -1.9457509e-06f});
+  p = __builtin_elementwise_fma(p, s2, (f2v){4.1109510e-05f, 4.1109510e-05f});
+  p = __builtin_elementwise_fma(p, s2, (f2v){-5.1180745e-04f, -5.1180745e-04f});
+  p = __builtin_elementwise_fma(p, s2, (f2v){4.2413287e-03f, 4.2413287e-03f});
+  p = __builtin_elementwise_fma(p, s2, (f2v){-2.5126988e-02f, -2.5126988e-02f});
+  p = __builtin_elementwise_fma(p, s2, (f2v){1.1113088e-01f, 1.1113088e-01f});
+  p = __builtin_elementwise_fma(p, s2, (f2v){-3.7536559e-01f, -3.7536559e-01f});
+  p = __builtin_elementwise_fma(p, s2, (f2v){1.1282845e+00f, 1.1282845e+00f});
+  f2v e = p * z;
+  e = (f2v){__builtin_amdgcn_fmed3f(e.x, -1.0f, 1.0f), __builtin_amdgcn_fmed3f(e.y, -1.0f, 1.0f)};
+  const f2v hx = x * 0.5f;
+  return __builtin_elementwise_fma(hx, e, hx);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f4& lo, const f4& hi) {
+  bf16x8 r;
+  r[0] = (__bf16)lo[0]; r[1] = (__bf16)lo[1]; r[2] = (__bf16)lo[2]; r[3] = (__bf16)lo[3];
+  r[4] = (__bf16)hi[0]; r[5] = (__bf16)hi[1]; r[6] = (__bf16)hi[2]; r[7] = (__bf16)hi[3];
+  return r;
+}
+
+// One hidden layer for the wave's two 16-point column tiles: acc[c][mt] (8 feature tiles x 2 point tiles).
+template <int KB /* 32-wide k blocks */, int ROW>
+__device__ __forceinline__ void layer_mfma(const unsigned char* __restrict__ w, const float* __restrict__ bias,
+                                           const bf16x8 (&bin)[2][4], f4 (&acc)[2][8], int lane) {
+  const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const f4 b4 = *reinterpret_cast<const f4*>(bias + 16 * mt + 4 * g);  // D rows 4g..4g+3 of this feature tile
+    acc[0][mt] = b4; acc[1][mt] = b4;
+    const unsigned char* row = w + (size_t)(16 * mt + i) * ROW + g * 16;
+#pragma unroll
+    for (int s = 0; s < KB; ++s) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(row + s * 64);
+      acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bin[0][s], acc[0][mt], 0, 0, 0);
+      acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bin[1][s], acc[1][mt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the weight reads of later tiles from being hoisted (VGPR pressure)
+  }
+}
+
+__device__ __forceinline__ void gelu_pack(const f4 (&acc)[2][8], bf16x8 (&bout)[2][4]) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f4 lo, hi;
+      {
+        const f4& a0 = acc[c][2 * s];
+        const f4& a1 = acc[c][2 * s + 1];
+        const f2v g0 = gelu2((f2v){a0[0], a0[1]}), g1 = gelu2((f2v){a0[2], a0[3]});
+        const f2v g2 = gelu2((f2v){a1[0], a1[1]}), g3 = gelu2((f2v){a1[2], a1[3]});
+        lo = (f4){g0.x, g0.y, g1.x, g1.y};
+        hi = (f4){g2.x, g2.y, g3.x, g3.y};
+      }
+      bout[c][s] = pack8(lo, hi);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// attrs row (16 floats per point): [0..2] color, [3] opacity, [4..7] rotation, [8..10] activated scale,
+// [11..13] xyz, [14..15] unused.  It doubles as the carrier of the earlier heads' outputs between heads: the "info"
+// vector a head sees is [position(3), attrs[0 .. n_extra)] with n_extra = 0, 3, 4, 8, 11.
+__global__ __launch_bounds__(MLP_THREADS, 2) void decoder_forward_kernel(const float* __restrict__ feat,
+                                                                         const float* __restrict__ pos, int N,
+                                                                         const unsigned char* __restrict__ packed,
+                                                                         float* attrs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wl = smem;  // HEAD_BYTES: weights + biases of one head
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+
+  // contiguous chunk of points per workgroup, 32-point slabs round-robin over its waves (the SAME wave revisits
+  // the same slab for every head, so the attrs rows it wrote are its own)
+  const int64_t per = (((int64_t)N + gridDim.x - 1) / gridDim.x + SLAB - 1) / SLAB * SLAB;
+  const int64_t cbeg = (int64_t)blockIdx.x * per;
+  const int64_t cend = min((int64_t)N, cbeg + per);
+
+  for (int head = 0; head < NHEAD; ++head) {
+    const int n_extra = head == 0 ? 0 : (head == 1 ? 3 : (head == 2 ? 4 : (head == 3 ? 8 : 11)));
+    __syncthreads();  // everyone is done with the previous head's weights (and its attrs stores are issued)
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(packed + (size_t)head * HEAD_BYTES);
+      uint4* dst = reinterpret_cast<uint4*>(wl);
+      for (int k = tid; k < HEAD_BYTES / 16; k += MLP_THREADS) dst[k] = src[k];
+    }
+    __threadfence_block();
+    __syncthreads();
+    const float* b1 = reinterpret_cast<const float*>(wl + OFF_B);
+    const float* b2 = b1 + HID;
+    const float* b3 = b2 + HID;
+    const float* b4 = b3 + HID;
+
+    for (int64_t p0 = cbeg + (int64_t)wv * SLAB; p0 < cend; p0 += (int64_t)MLP_WAVES * SLAB) {
+      // ---- inputs: k-block 0 = 32 plane features, k-block 1 = info slots 4g..4g+3 (upper half of the block zero)
+      bf16x8 bin[2][4];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int64_t pt = p0 + 16 * c + j;
+        const bool ok = pt < cend;
+        f4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0}, inf = {0, 0, 0, 0};
+        if (ok) {
+          lo = *reinterpret_cast<const f4*>(feat + pt * 32 + 4 * g);
+          hi = *reinterpret_cast<const f4*>(feat + pt * 32 + 16 + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int q = 4 * g + e;  // info slot
+            float v = 0.0f;
+            if (q < 3) v = pos[pt * 3 + q];
+            else if (q - 3 < n_extra) v = attrs[pt * 16 + (q - 3)];
+            inf[e] = v;
+          }
+        }
+        const f4 z = {0, 0, 0, 0};
+        bin[c][0] = pack8(lo, hi);
+        bin[c][1] = pack8(inf, z);
+      }
+      f4 acc[2][8];
+      bf16x8 bh[2][4];
+      layer_mfma<2, ROW1>(wl + OFF_W1, b1, bin, acc, lane);
+      gelu_pack(acc, bh);
+      layer_mfma<4, ROW2>(wl + OFF_W2, b2, bh, acc, lane);
+      gelu_pack(acc, bh);
+      layer_mfma<4, ROW2>(wl + OFF_W3, b3, bh, acc, lane);
+      gelu_pack(acc, bh);
+      // ---- output layer: one feature tile (weight rows >= out_dim are zero)
+      f4 out[2];
+      {
+        const f4 bb = *reinterpret_cast<const f4*>(b4 + 4 * g);
+        out[0] = bb; out[1] = bb;
+        const unsigned char* row = wl + OFF_W4 + (size_t)j * ROW2 + g * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(row + s * 64);
+          out[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh[0][s], out[0], 0, 0, 0);
+          out[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh[1][s], out[1], 0, 0, 0);
+        }
+      }
+      // lane group 0 holds output features 0..3 of point j (D rows 0..3)
+      if (g == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int64_t pt = p0 + 16 * c + j;
+          if (pt >= cend) continue;
+          float* arow = attrs + pt * 16;
+          const f4 o = out[c];
+          if (head == 0) {
+            arow[0] = o[0]; arow[1] = o[1]; arow[2] = o[2];
+          } else if (head == 1) {
+            arow[3] = o[0];
+          } else if (head == 2) {
+            arow[4] = o[0]; arow[5] = o[1]; arow[6] = o[2]; arow[7] = o[3];
+          } else if (head == 3) {  // -softplus(s + 5) - 2.5   (torch.nn.Softplus: beta 1, threshold 20)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              const float v = o[q] + 5.0f;
+              const float sp = v > 20.0f ? v : log1pf(expf(v));
+              arow[8 + q] = -sp - 2.5f;
+            }
+          } else {                 // xyz = head * 0.01 + position
+            arow[11] = o[0] * 0.01f + pos[pt * 3]; arow[12] = o[1] * 0.01f + pos[pt * 3 + 1];
+            arow[13] = o[2] * 0.01f + pos[pt * 3 + 2];
+            arow[14] = 0.0f; arow[15] = 0.0f;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t ggd_decoder_packed_bytes(void) { return (size_t)NHEAD * HEAD_BYTES; }
+
+extern "C" int ggd_decoder_forward(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
+                                   const void* packed_weights, float* attrs) {
+  if (!ctx) return GGD_E_INVALID;
+  if (N < 0) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_forward: N < 0");
+  if (N == 0) return GGD_OK;
+  if (!feat || !pos || !packed_weights || !attrs) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_forward: NULL pointer");
+  const size_t lds = HEAD_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_forward_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  int grid = (N + MLP_WAVES * SLAB - 1) / (MLP_WAVES * SLAB);  // at least one slab per wave
+  if (grid > 256) grid = 256;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(decoder_forward_kernel, dim3(grid), dim3(MLP_THREADS), lds, static_cast<hipStream_t>(stream), feat,
+                     pos, N, static_cast<const unsigned char*>(packed_weights), attrs);
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}

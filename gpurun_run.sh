@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -4
-timeout 600 python scripts/profile_train.py 2>&1 | grep -v amdgpu | cut -c1-200 | tail -24
+timeout 300 python -m pytest tests/test_decoder_gpu.py -m gpu -q -x 2>&1 | tail -5
+timeout 300 python scripts/decode_timing.py 2>&1 | grep -v amdgpu

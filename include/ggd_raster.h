@@ -165,8 +165,8 @@ int ggd_debug_unsorted(ggd_ctx* ctx, void* stream, uint64_t* keys, uint32_t* val
 /* Tuning / experiment knobs (do not change results beyond the documented tolerances).  Returns GGD_E_INVALID for an
  * unknown option or value. */
 enum {
-  GGD_OPT_EXP_MODE = 0,   /* blend exp(): 0 = ocml expf (<=1 ulp, default), 1 = native 2^(x*log2e) (fast, ~3 ulp),
-                             2 = compensated 2^x (v_exp_f32 + product-residual correction, ~1 ulp) */
+  GGD_OPT_EXP_MODE = 0,   /* blend exp(): 0 = ocml expf (<=1 ulp), 1 = native 2^(x*log2e) (fast, ~3 ulp),
+                             2 (default) = compensated 2^x (v_exp_f32 + product-residual correction, ~1 ulp) */
   GGD_OPT_BLEND_CULL = 1, /* 1 (default) = skip records whose alpha cannot reach 1/255 anywhere in the tile */
   GGD_OPT_BINNING = 2,    /* how the per-tile sorted lists are built (results are identical):
                              0 = duplicateWithKeys + 64-bit (tile|depth) radix sort + identifyTileRanges,
@@ -195,6 +195,19 @@ int ggd_triplane_forward(ggd_ctx* ctx, void* stream, const float* planes_cl, int
                          const float* pos, int32_t N, float box_warp, float* out);
 int ggd_triplane_backward(ggd_ctx* ctx, void* stream, int32_t C, int32_t H, int32_t W, const float* pos, int32_t N,
                           float box_warp, const float* dout, float* dplanes_cl);
+
+/*
+ * Fused per-point decoder, inference (bf16 MFMA, fp32 accumulate): the 5 chained `Decoder` MLPs of
+ * main/decoder_models/sequential_decoder_reverse.py:68-85 in ONE launch.
+ *   feat  [N,32]  mean-of-planes features (ggd_triplane_forward)      pos [N,3] positions
+ *   packed_weights : ggd_decoder_packed_bytes() bytes, the LDS image of the 5 heads (bf16 weight rows pre-permuted to
+ *                    the MFMA operand order + fp32 biases; built by gaussian_gan_decoder_amd.fused_decoder.pack_weights)
+ *   attrs [N,16]  out: [0..2] color, [3] opacity, [4..7] rotation, [8..10] scale (= -softplus(s+5)-2.5),
+ *                      [11..13] xyz (= head*0.01 + pos), [14..15] zero
+ */
+size_t ggd_decoder_packed_bytes(void);
+int ggd_decoder_forward(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
+                        const void* packed_weights, float* attrs);
 
 /* Per-stage device time (ms, hipEvent pairs on `stream`) of the most recent forward_geometry / forward_render /
  * backward call when profiling is on.  Stage names: ggd_stage_name(i), i in [0, ggd_stage_count()). */

@@ -40,3 +40,48 @@ def test_decoder_forward_backward_runs_on_gpu(native_lib):
     dec_cpu = SequentialDecoderReverse(); dec_cpu.load_state_dict(dec.state_dict())
     out_cpu = dec_cpu(planes.detach().cpu(), pos.cpu())
     assert (out.xyz.detach().cpu() - out_cpu.xyz).abs().max().item() <= 1e-4
+
+
+def _bf16_reference(dec, feats, pos):
+    """PyTorch emulation of the kernel's numerics: every layer input and weight rounded to bf16, fp32 accumulate."""
+    r = lambda t: t.to(torch.bfloat16).float()
+
+    def mlp(head, x):
+        for k in (0, 2, 4):
+            lin = head.backbone[k]
+            x = torch.nn.functional.gelu(r(x) @ r(lin.weight).t() + lin.bias)
+        lin = head.backbone[6]
+        return r(x) @ r(lin.weight).t() + lin.bias
+    info = pos
+    color = mlp(dec.color_decoder, torch.cat([feats, info], 1)); info = torch.cat([info, color], 1)
+    opac = mlp(dec.opacity_decoder, torch.cat([feats, info], 1)); info = torch.cat([info, opac], 1)
+    rot = mlp(dec.rotation_decoder, torch.cat([feats, info], 1)); info = torch.cat([info, rot], 1)
+    scale = dec.activate_scale(mlp(dec.scale_decoder, torch.cat([feats, info], 1))); info = torch.cat([info, scale], 1)
+    xyz = mlp(dec.xyz_decoder, torch.cat([feats, info], 1)) * 0.01 + pos
+    return dict(color=color, opacity=opac, rotation=rot, scale=scale, xyz=xyz)
+
+
+@pytest.mark.parametrize("N", [1, 33, 5000, 100003])
+def test_fused_decoder_matches_torch(native_lib, N):
+    from gaussian_gan_decoder_amd.fused_decoder import FusedDecoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    dec = SequentialDecoderReverse().to(dev)
+    for p in dec.parameters():            # make the heads' outputs O(1) so the comparison is meaningful
+        if p.dim() == 2:
+            p.data *= 1.5
+    planes = torch.randn(3, 32, 64, 64, device=dev)
+    pos = torch.rand(N, 3, device=dev) - 0.5
+    fused = FusedDecoder(dec)
+    out = fused(planes, pos)
+    feats = triplane_mean(planes, pos, 1.0)
+    with torch.no_grad():
+        emu = _bf16_reference(dec, feats, pos)
+        ref = dec(planes, pos)
+    for name in ("color", "opacity", "rotation", "scale", "xyz"):
+        got = getattr(out, name)
+        assert got.shape == emu[name].shape, name
+        # tight vs the bf16 emulation (same rounding points; differences = accumulation order + GELU 1.5e-7)
+        assert (got - emu[name]).abs().max().item() <= 2e-3 * max(1.0, emu[name].abs().max().item()), name
+        # loose vs the fp32 module (bf16 has 8 mantissa bits; 4 layers deep)
+        assert (got - getattr(ref, name)).abs().max().item() <= 5e-2 * max(1.0, getattr(ref, name).abs().max().item()), name
