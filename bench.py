@@ -212,7 +212,9 @@ def main():
                  "ms_per_iter": t_train / args.train_iters * 1e3, "global_batch": spg * world,
                  "scenes_per_gpu": spg, "points_per_scene": args.train_points, "image": "512x512",
                  "allreduce_bytes": nparam * 4 if world > 1 else 0,
-                 "step": "decoder MLPs (PyTorch fp32) -> activations -> HIP raster fwd -> L1+L2 -> bwd -> flat all-reduce -> Adam"}
+                 "mlp_dtype": "fp32",
+                 "step": "tri-plane gather (HIP) -> decoder MLPs (PyTorch fp32; bf16 autocast measured: no gain, the "
+                         "tall-skinny GEMMs are HBM-bound) -> activations -> HIP raster fwd -> L1+L2 -> bwd -> flat all-reduce -> Adam"}
         del tr, batches
     if rank != 0:
         if dist is not None:

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python -m pytest tests/test_decoder_gpu.py -m gpu -q -x 2>&1 | tail -5
-timeout 300 python scripts/decode_timing.py 2>&1 | grep -v amdgpu
+timeout 600 python bench.py --no-cpu-baseline --no-decode --steps 20 --warmup 5 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['train'])"
+timeout 600 python bench.py --no-cpu-baseline --no-decode --steps 20 --warmup 5 --train-amp | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['train'])"
