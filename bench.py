@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backward", action="store_true", help="also time forward+backward (reported under 'extra')")
     ap.add_argument("--no-train", action="store_true", help="skip the data-parallel train-step section")
+    ap.add_argument("--no-decode", action="store_true", help="skip the fused decode + render section (config 3)")
     ap.add_argument("--train-iters", type=int, default=8)
     ap.add_argument("--train-points", type=int, default=500_000, help="positions per scene (reference: 500 000)")
     ap.add_argument("--scenes-per-gpu", type=int, default=4)
@@ -186,6 +187,56 @@ def main():
             stage_ms[k] = v / nprof
     ctx.set_profiling(False)
 
+    # ---- BASELINE config 3: decode ~1M Gaussians (tri-plane gather + fused bf16-MFMA decoder) and render at 1024^2
+    decode = None
+    if not args.no_decode and rank == 0:
+        from gaussian_gan_decoder_amd.decoder import SequentialDecoderReverse, triplane_mean
+        from gaussian_gan_decoder_amd.fused_decoder import FusedDecoder
+        from gaussian_gan_decoder_amd.gaussian_model import GaussianModel
+        from gaussian_gan_decoder_amd.gaussian_renderer import render_simple
+        from gaussian_gan_decoder_amd.synthetic import make_camera
+        torch.manual_seed(0)
+        dec = SequentialDecoderReverse().to(dev)
+        fused = FusedDecoder(dec)
+        g = torch.Generator().manual_seed(5)
+        planes = torch.randn(3, 32, 256, 256, generator=g).to(dev)
+        d = torch.randn(1_000_000, 3, generator=g)
+        positions = (d / d.norm(dim=1, keepdim=True) * 0.3
+                     * torch.clip(1 + 0.1 * torch.randn(1_000_000, 1, generator=g), 0, 1)).to(dev)
+        cam1k = make_camera(1024, 12.0, device=dev)
+        pc = GaussianModel(0)
+
+        def decode_render():
+            with torch.no_grad():
+                o = fused(planes, positions)
+                pc._xyz, pc._scaling, pc._rotation, pc._opacity = o.xyz, o.scale, o.rotation, o.opacity
+                pc._features_dc = o.color.unsqueeze(1)
+                return render_simple(cam1k, pc, bg_color=sc.bg)["render"]
+        for _ in range(5):
+            decode_render()
+        torch.cuda.synchronize(dev)
+        td = time.perf_counter()
+        nd = 50
+        for _ in range(nd):
+            decode_render()
+        torch.cuda.synchronize(dev)
+        td = (time.perf_counter() - td) / nd
+        feats = triplane_mean(planes, positions, 1.0)
+        for _ in range(3):
+            fused.decode_features(feats, positions)
+        torch.cuda.synchronize(dev)
+        tm = time.perf_counter()
+        for _ in range(nd):
+            fused.decode_features(feats, positions)
+        torch.cuda.synchronize(dev)
+        tm = (time.perf_counter() - tm) / nd
+        mlp_flops = 2 * 192512 * 1_000_000
+        decode = {"frames_per_s": 1.0 / td, "ms_per_frame": td * 1e3, "points": 1_000_000, "image": "1024x1024",
+                  "pipeline": "tri-plane gather (HIP) -> fused 5-head decoder (bf16 MFMA) -> activations (torch) -> HIP raster",
+                  "mlp_ms": tm * 1e3, "mlp_TFLOPs": mlp_flops / tm / 1e12,
+                  "mlp_frac_of_bf16_dense_peak": mlp_flops / tm / 2.5e15}
+        del dec, fused, planes, positions
+
     # ---- data-parallel decoder train step (BASELINE configs 3/5): scenes_per_gpu scenes per rank, 512x512,
     #      decoder MLPs -> activations -> raster fwd -> L1+L2 -> bwd -> ONE flat RCCL all-reduce -> Adam
     train = None
@@ -252,6 +303,8 @@ def main():
         "whole_frame": {"algorithmic_bytes": whole, "GBps": whole / (ms_per_step * 1e-3) / 1e9,
                         "frac_of_hbm_peak": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
+    if decode is not None:
+        result["decode_render"] = decode
     if train is not None:
         result["train"] = train
     if extra:
