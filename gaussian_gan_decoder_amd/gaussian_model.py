@@ -70,6 +70,15 @@ class GaussianModel:
     def get_covariance(self, scaling_modifier=1):
         return self.covariance_activation(self.get_scaling, scaling_modifier, self._rotation)
 
+    def save_ply(self, path):
+        """Binary PLY in the reference's field order (gaussian_model.py:281-302), raw pre-activation values."""
+        from .ply_io import save_ply
+        save_ply(path, self)
+
+    def load_ply(self, path, device="cpu"):
+        from .ply_io import load_ply
+        return load_ply(path, self, device)
+
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1
