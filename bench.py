@@ -211,7 +211,7 @@ def main():
                 o = fused(planes, positions)
                 pc._xyz, pc._scaling, pc._rotation, pc._opacity = o.xyz, o.scale, o.rotation, o.opacity
                 pc._features_dc = o.color.unsqueeze(1)
-                return render_simple(cam1k, pc, bg_color=sc.bg)["render"]
+                return render_simple(cam1k, pc, bg_color=sc.bg, fused_activations=True)["render"]
         for _ in range(5):
             decode_render()
         torch.cuda.synchronize(dev)
@@ -232,7 +232,7 @@ def main():
         tm = (time.perf_counter() - tm) / nd
         mlp_flops = 2 * 192512 * 1_000_000
         decode = {"frames_per_s": 1.0 / td, "ms_per_frame": td * 1e3, "points": 1_000_000, "image": "1024x1024",
-                  "pipeline": "tri-plane gather (HIP) -> fused 5-head decoder (bf16 MFMA) -> activations (torch) -> HIP raster",
+                  "pipeline": "tri-plane gather (HIP) -> fused 5-head decoder (bf16 MFMA) -> HIP raster (activation prologue fused)",
                   "mlp_ms": tm * 1e3, "mlp_TFLOPs": mlp_flops / tm / 1e12,
                   "mlp_frac_of_bf16_dense_peak": mlp_flops / tm / 2.5e15}
         del dec, fused, planes, positions
@@ -243,7 +243,7 @@ def main():
     if not args.no_train:
         from gaussian_gan_decoder_amd.train import DecoderTrainer, make_scene_batch
         spg = args.scenes_per_gpu
-        tr = DecoderTrainer(dev, n_scenes_total=spg * world, image_size=512)
+        tr = DecoderTrainer(dev, n_scenes_total=spg * world, image_size=512, fused_activations=True)
         my_scenes = list(range(rank * spg, (rank + 1) * spg))
         batches = [make_scene_batch(my_scenes, args.train_points, 512, dev, seed=i) for i in range(2)]
         for i in range(2):
@@ -265,7 +265,7 @@ def main():
                  "allreduce_bytes": nparam * 4 if world > 1 else 0,
                  "mlp_dtype": "fp32",
                  "step": "tri-plane gather (HIP) -> decoder MLPs (PyTorch fp32; bf16 autocast measured: no gain, the "
-                         "tall-skinny GEMMs are HBM-bound) -> activations -> HIP raster fwd -> L1+L2 -> bwd -> flat all-reduce -> Adam"}
+                         "tall-skinny GEMMs are HBM-bound) -> HIP raster fwd (activations fused) -> L1+L2 -> bwd -> flat all-reduce -> Adam"}
         del tr, batches
     if rank != 0:
         if dist is not None:

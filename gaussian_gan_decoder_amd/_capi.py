@@ -26,7 +26,7 @@ class Params(C.Structure):
                 ("height", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("scale_modifier", C.c_float), ("prefiltered", C.c_int32), ("debug", C.c_int32),
                 ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
-                ("bg", C.c_void_p)]
+                ("bg", C.c_void_p), ("raw_attributes", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class GeomView(C.Structure):
@@ -75,7 +75,7 @@ def load():
         lib.ggd_version.restype = C.c_char_p
         lib.ggd_forward_geometry.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 7 + [vp, vp, C.POINTER(i64)]
         lib.ggd_forward_render.argtypes = [vp, vp, C.POINTER(Params), vp, i64, vp, vp, vp]
-        lib.ggd_backward.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 6 + [vp, vp, vp, vp, i64, vp] + [vp] * 8
+        lib.ggd_backward.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 7 + [vp, vp, vp, vp, i64, vp] + [vp] * 8
         lib.ggd_mark_visible.argtypes = [vp, vp, i32, vp, vp, vp, vp]
         lib.ggd_debug_unsorted.argtypes = [vp, vp, vp, vp, i64]
         lib.ggd_triplane_forward.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, C.c_float, vp]

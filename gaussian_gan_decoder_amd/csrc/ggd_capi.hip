@@ -223,6 +223,8 @@ extern "C" int ggd_forward_geometry(ggd_ctx* ctx, void* stream, const ggd_params
   *num_rendered = 0;
   if (prm->P == 0) return GGD_OK;
   if (!geom_buf || !radii || !opacities) return ggd_fail(ctx, GGD_E_INVALID, "geom_buf / radii / opacities is NULL");
+  if (prm->raw_attributes && cov3D_precomp)
+    return ggd_fail(ctx, GGD_E_INVALID, "raw_attributes needs scales/rotations (no cov3D_precomp)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   ggd_geom_view gv;
   ggd_geom_layout(prm->P, &gv);
@@ -364,7 +366,7 @@ extern "C" int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* 
 
 // ---- backward --------------------------------------------------------------------------------------------------
 extern "C" int ggd_backward(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D,
-                            const float* shs, const float* colors_precomp, const float* scales,
+                            const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
                             const float* rotations, const float* cov3D_precomp, const int32_t* radii,
                             const void* geom_buf, const void* binning_buf, const void* img_buf, int64_t R,
                             const float* dL_dpix, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
@@ -379,6 +381,8 @@ extern "C" int ggd_backward(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
   if (!radii || !geom_buf || !img_buf || !dL_dpix || !dL_dmeans2D || !dL_dcolors || !dL_dopacity ||
       !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drots || (prm->M > 0 && !dL_dsh) || (R > 0 && !binning_buf))
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_backward: NULL buffer");
+  if (prm->raw_attributes && (!opacities || cov3D_precomp))
+    return ggd_fail(ctx, GGD_E_INVALID, "raw_attributes needs opacities and scales/rotations (no cov3D_precomp)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   ggd_geom_view gv; ggd_binning_view bv; ggd_img_view iv;
   ggd_geom_layout(P, &gv); ggd_binning_layout(R, &bv); ggd_img_layout(prm->width, prm->height, &iv);
@@ -414,7 +418,7 @@ extern "C" int ggd_backward(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
   }
   {
     StageTimer t(ctx, ST_PREPROCESS_BWD, s);
-    rc = ggd_launch_preprocess_backward(ctx, s, *prm, means3D, shs, colors_precomp, scales, rotations,
+    rc = ggd_launch_preprocess_backward(ctx, s, *prm, means3D, shs, colors_precomp, opacities, dL_dopacity, scales, rotations,
                                         cov3D_precomp, radii, shs ? clamped : nullptr, dL_dmeans2D, dL_dconic,
                                         dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots);
     if (rc != GGD_OK) return rc;

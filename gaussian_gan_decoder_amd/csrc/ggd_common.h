@@ -99,7 +99,8 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
                               const uint32_t* n_contrib, const float* dL_dpix, float* dL_dmean2D /*[P,3]*/,
                               float* dL_dconic /*[P,4]*/, float* dL_dopacity, float* dL_dcolors);
 int ggd_launch_preprocess_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const float* means3D,
-                                   const float* shs, const float* colors_precomp, const float* scales,
+                                   const float* shs, const float* colors_precomp, const float* opacities,
+                                   float* dL_dopacity, const float* scales,
                                    const float* rotations, const float* cov3D_precomp, const int32_t* radii,
                                    const uint8_t* clamped, const float* dL_dmean2D, const float* dL_dconic,
                                    const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,

@@ -30,6 +30,14 @@ __device__ __forceinline__ Mat16 load_mat(const float* __restrict__ p) {
   return r;
 }
 
+// Activation prologue of the reference's GaussianModel getters (gaussian_model.py:100-121), fused on request.
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float4 act_normalize(float4 q, float& norm) {
+  norm = sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w));
+  const float d = fmaxf(norm, 1e-12f);  // torch.nn.functional.normalize: v / max(||v||, eps)
+  return make_float4(q.x / d, q.y / d, q.z / d, q.w / d);
+}
+
 // Sigma = R S S R^T, stored (S00,S01,S02,S11,S12,S22); quaternion (w,x,y,z) used as given (not re-normalised).
 __device__ __forceinline__ void cov3d_from_scale_rot(const float s3[3], float mod, const float4 q, float cov6[6]) {
   const float r = q.x, x = q.y, y = q.z, z = q.w;

@@ -13,7 +13,7 @@ namespace {
 using namespace ggdm;
 
 __global__ __launch_bounds__(256) void preprocess_kernel(
-    int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered,
+    int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered, int raw,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos_p,
     const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -50,8 +50,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 #pragma unroll
       for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * (size_t)i + k];
     } else {
-      const float s3[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
-      const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+      float s3[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
+      float4 q = reinterpret_cast<const float4*>(rotations)[i];
+      if (raw) {
+        float nrm;
+        s3[0] = expf(s3[0]); s3[1] = expf(s3[1]); s3[2] = expf(s3[2]);
+        q = act_normalize(q, nrm);
+      }
       cov3d_from_scale_rot(s3, mod, q, c6);
     }
     const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         }
         out.x = px; out.y = py;
         out.conA = c * det_inv; out.conB = -b * det_inv; out.conC = a * det_inv;
-        out.opacity = opacities[i];
+        out.opacity = raw ? act_sigmoid(opacities[i]) : opacities[i];
         out.r = rgb[0]; out.g = rgb[1]; out.b = rgb[2];
         out.depth = t[2];
         out.radius = irad;
@@ -129,7 +134,7 @@ int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, co
   if (prm.P == 0) return GGD_OK;
   const int grid = (prm.P + 255) / 256;
   hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, s, prm.P, prm.M, prm.sh_degree, prm.width,
-                     prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.viewmatrix,
+                     prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.raw_attributes, prm.viewmatrix,
                      prm.projmatrix, prm.campos, means3D, shs, colors_precomp, opacities, scales, rotations,
                      cov3D_precomp, splat, tiles_touched, clamped, radii, depth_keys, visible_count, trap_flag);
   GGD_HIP(hipGetLastError());

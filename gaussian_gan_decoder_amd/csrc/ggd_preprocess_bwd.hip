@@ -15,7 +15,8 @@ namespace {
 using namespace ggdm;
 
 __global__ __launch_bounds__(256) void preprocess_backward_kernel(
-    int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod,
+    int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int raw,
+    const float* __restrict__ opacities_raw, float* __restrict__ dL_dopacity,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos_p,
     const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
@@ -32,7 +33,8 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
   const float p[3] = {means3D[3 * ii], means3D[3 * ii + 1], means3D[3 * ii + 2]};
 
   float c6[6];
-  float4 q = make_float4(0, 0, 0, 0);
+  float4 q = make_float4(0, 0, 0, 0), q_raw = make_float4(0, 0, 0, 0);
+  float q_norm = 1.0f;
   float s3[3] = {0, 0, 0};
   if (cov3D_precomp) {
 #pragma unroll
@@ -40,6 +42,11 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
   } else {
     s3[0] = scales[3 * ii]; s3[1] = scales[3 * ii + 1]; s3[2] = scales[3 * ii + 2];
     q = reinterpret_cast<const float4*>(rotations)[i];
+    if (raw) {
+      q_raw = q;
+      s3[0] = expf(s3[0]); s3[1] = expf(s3[1]); s3[2] = expf(s3[2]);
+      q = act_normalize(q, q_norm);
+    }
     cov3d_from_scale_rot(s3, mod, q, c6);
   }
 
@@ -207,6 +214,9 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
 #pragma unroll
       for (int j = 0; j < 3; ++j) Q[j][k] = dM[k][j] * s[k];
     }
+    if (raw) {  // d exp(x) = exp(x)
+      dscale[0] *= s3[0]; dscale[1] *= s3[1]; dscale[2] *= s3[2];
+    }
     dL_dscales[3 * ii] = dscale[0]; dL_dscales[3 * ii + 1] = dscale[1]; dL_dscales[3 * ii + 2] = dscale[2];
     float4 dq;
     dq.x = 2.0f * (-z * Q[0][1] + y * Q[0][2] + z * Q[1][0] - x * Q[1][2] - y * Q[2][0] + x * Q[2][1]);
@@ -216,14 +226,26 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
                    z * Q[2][1] - 2.0f * y * Q[2][2]);
     dq.w = 2.0f * (-2.0f * z * Q[0][0] - r * Q[0][1] + x * Q[0][2] + r * Q[1][0] - 2.0f * z * Q[1][1] +
                    y * Q[1][2] + x * Q[2][0] + y * Q[2][1]);
+    if (raw) {  // through q_hat = q / max(||q||, eps): (g - q_hat (q_hat . g)) / max(||q||, eps)
+      const float dotg = (q.x * dq.x + q.y * dq.y) + (q.z * dq.z + q.w * dq.w);
+      const float dn = fmaxf(q_norm, 1e-12f);
+      dq = make_float4((dq.x - q.x * dotg) / dn, (dq.y - q.y * dotg) / dn, (dq.z - q.z * dotg) / dn,
+                       (dq.w - q.w * dotg) / dn);
+      (void)q_raw;
+    }
     reinterpret_cast<float4*>(dL_drots)[i] = dq;
+  }
+  if (raw) {  // sigmoid'(x) = s (1 - s), applied in place to the blend's dL/d(opacity)
+    const float sg = act_sigmoid(opacities_raw[i]);
+    dL_dopacity[i] = dL_dopacity[i] * (sg * (1.0f - sg));
   }
 }
 
 }  // namespace
 
 int ggd_launch_preprocess_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const float* means3D,
-                                   const float* shs, const float* colors_precomp, const float* scales,
+                                   const float* shs, const float* colors_precomp, const float* opacities,
+                                   float* dL_dopacity, const float* scales,
                                    const float* rotations, const float* cov3D_precomp, const int32_t* radii,
                                    const uint8_t* clamped, const float* dL_dmean2D, const float* dL_dconic,
                                    const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
@@ -231,7 +253,7 @@ int ggd_launch_preprocess_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params
   if (prm.P == 0) return GGD_OK;
   hipLaunchKernelGGL(preprocess_backward_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, s, prm.P, prm.M,
                      prm.sh_degree, prm.width, prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier,
-                     prm.viewmatrix, prm.projmatrix, prm.campos, means3D, shs, colors_precomp, scales, rotations,
+                     prm.raw_attributes, opacities, dL_dopacity, prm.viewmatrix, prm.projmatrix, prm.campos, means3D, shs, colors_precomp, scales, rotations,
                      cov3D_precomp, radii, clamped, dL_dmean2D, dL_dconic, dL_dcolors, dL_dmeans3D, dL_dcov3D,
                      dL_dsh, dL_dscales, dL_drots);
   GGD_HIP(hipGetLastError());

@@ -29,8 +29,9 @@ def _screenspace_points(pc):
     return pts
 
 
-def _settings(viewpoint_camera, pc, bg_color, scaling_modifier, debug):
+def _settings(viewpoint_camera, pc, bg_color, scaling_modifier, debug, raw_attributes=False):
     return GaussianRasterizationSettings(
+        raw_attributes=raw_attributes,
         image_height=int(viewpoint_camera.image_height),
         image_width=int(viewpoint_camera.image_width),
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5),
@@ -75,11 +76,15 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
 
 def render_simple(viewpoint_camera, pc, bg_color: torch.Tensor, xyz_offset=None, scaling_modifier=1.0,
-                  override_color=None, debug=False):
+                  override_color=None, debug=False, fused_activations=False):
     """Decoder-path render (reference :105-186): scale/rotation always from the model, SH unless override_color.
-    "alpha" and "depth" are the radii placeholders the reference returns (:184-185)."""
+    "alpha" and "depth" are the radii placeholders the reference returns (:184-185).
+    fused_activations=True (extension): hand the RAW `_opacity/_scaling/_rotation` to the
+    rasterizer, which applies sigmoid / exp / normalize (and their Jacobians in the backward) inside its kernels
+    instead of three torch elementwise passes each way."""
     screenspace_points = _screenspace_points(pc)
-    rasterizer = GaussianRasterizer(_settings(viewpoint_camera, pc, bg_color, scaling_modifier, debug))
+    rasterizer = GaussianRasterizer(_settings(viewpoint_camera, pc, bg_color, scaling_modifier, debug,
+                                              raw_attributes=fused_activations))
     means3D = pc.get_xyz
     if xyz_offset is not None:
         means3D = means3D + xyz_offset
@@ -88,8 +93,12 @@ def render_simple(viewpoint_camera, pc, bg_color: torch.Tensor, xyz_offset=None,
         shs = pc.get_features
     else:
         colors_precomp = override_color
+    if fused_activations:
+        opacities, scales, rotations = pc._opacity, pc._scaling, pc._rotation
+    else:
+        opacities, scales, rotations = pc.get_opacity, pc.get_scaling, pc.get_rotation
     rendered_image, radii = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs,
-                                       colors_precomp=colors_precomp, opacities=pc.get_opacity,
-                                       scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None)
+                                       colors_precomp=colors_precomp, opacities=opacities,
+                                       scales=scales, rotations=rotations, cov3D_precomp=None)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "alpha": radii, "depth": radii}

@@ -43,6 +43,8 @@ class GaussianRasterizationSettings(NamedTuple):
     campos: torch.Tensor
     prefiltered: bool
     debug: bool
+    raw_attributes: bool = False  # extension (default = upstream behaviour): opacities / scales / rotations are the raw
+    #                               decoder outputs; sigmoid / exp / normalize are fused into the kernels (fwd + bwd)
 
 
 def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
@@ -73,7 +75,8 @@ def _params(rs: GaussianRasterizationSettings, P: int, M: int, device, keep: lis
     keep += [view, proj, campos, bg]
     return _capi.Params(P, M, int(rs.sh_degree), int(rs.image_width), int(rs.image_height), float(rs.tanfovx),
                         float(rs.tanfovy), float(rs.scale_modifier), int(bool(rs.prefiltered)),
-                        int(bool(rs.debug)), view.data_ptr(), proj.data_ptr(), campos.data_ptr(), bg.data_ptr())
+                        int(bool(rs.debug)), view.data_ptr(), proj.data_ptr(), campos.data_ptr(), bg.data_ptr(),
+                        int(bool(getattr(rs, "raw_attributes", False))), 0)
 
 
 def _require_cuda(t: torch.Tensor):
@@ -84,7 +87,7 @@ def _require_cuda(t: torch.Tensor):
 
 def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
                                cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
-                               sh, degree, campos, prefiltered, debug):
+                               sh, degree, campos, prefiltered, debug, raw_attributes=False):
     """== upstream `_C.rasterize_gaussians(...)`: returns
     (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer)."""
     _require_cuda(means3D)
@@ -106,7 +109,7 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
             raise ValueError("sh must have dimensions (num_points, num_coeffs, 3)")
         M = sh_c.size(1)
     rs = GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier,
-                                       viewmatrix, projmatrix, degree, campos, prefiltered, debug)
+                                       viewmatrix, projmatrix, degree, campos, prefiltered, debug, raw_attributes)
     keep: list = []
     prm = _params(rs, P, M, dev, keep)
     ctx = _capi.context_for(dev)
@@ -131,7 +134,8 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
 
 def rasterize_gaussians_backward_native(bg, means3D, radii, colors_precomp, scales, rotations, scale_modifier,
                                         cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, dL_dout_color, sh,
-                                        degree, campos, geomBuffer, R, binningBuffer, imgBuffer, debug):
+                                        degree, campos, geomBuffer, R, binningBuffer, imgBuffer, debug,
+                                        raw_attributes=False, opacities=None):
     """== upstream `_C.rasterize_gaussians_backward(...)`: returns
     (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
     _require_cuda(means3D)
@@ -148,7 +152,8 @@ def rasterize_gaussians_backward_native(bg, means3D, radii, colors_precomp, scal
     g = _f32c(dL_dout_color, "dL_dout_color", dev)
     M = sh_c.size(1) if sh_c is not None else 0
     rs = GaussianRasterizationSettings(H, W, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix, degree,
-                                       campos, False, debug)
+                                       campos, False, debug, raw_attributes)
+    op_c = _f32c(opacities, "opacities", dev) if (raw_attributes and opacities is not None) else None
     keep: list = []
     prm = _params(rs, P, M, dev, keep)
     ctx = _capi.context_for(dev)
@@ -165,7 +170,7 @@ def rasterize_gaussians_backward_native(bg, means3D, radii, colors_precomp, scal
     if P > 0:
         with torch.cuda.device(dev):
             ctx.check(lib.ggd_backward(ctx.handle, _stream(dev), C.byref(prm), _ptr(means3D), _ptr(sh_c), _ptr(col_c),
-                                       _ptr(sc_c), _ptr(rot_c), _ptr(cov_c), _ptr(radii), _ptr(geomBuffer),
+                                       _ptr(op_c), _ptr(sc_c), _ptr(rot_c), _ptr(cov_c), _ptr(radii), _ptr(geomBuffer),
                                        _ptr(binningBuffer), _ptr(imgBuffer), int(R), _ptr(g), _ptr(dL_dmeans2D),
                                        _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
                                        _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations)))
@@ -195,23 +200,25 @@ class _RasterizeGaussians(torch.autograd.Function):
         num_rendered, color, radii, geom, binning, img = rasterize_gaussians_native(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
-            rs.campos, rs.prefiltered, rs.debug)
+            rs.campos, rs.prefiltered, rs.debug, getattr(rs, "raw_attributes", False))
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning,
-                              img)
+                              img, opacities)
         ctx.mark_non_differentiable(radii)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
         rs = ctx.raster_settings
-        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, opacities = \
+            ctx.saved_tensors
+        raw = getattr(rs, "raw_attributes", False)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = rasterize_gaussians_backward_native(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geom,
-            ctx.num_rendered, binning, img, rs.debug)
+            ctx.num_rendered, binning, img, rs.debug, raw, opacities if raw else None)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                 grad_rotations, grad_cov3Ds_precomp, None)
 

@@ -62,7 +62,7 @@ class DecoderTrainer:
 
     def __init__(self, device, n_scenes_total: int, plane_res: int = 256, plane_channels: int = 32,
                  hidden_dim: int = 128, lr: float = 9e-5, image_size: int = 512, render_fn=None, seed: int = 0,
-                 l1_weight: float = 0.2, l2_weight: float = 1.0, process_group=None):
+                 l1_weight: float = 0.2, l2_weight: float = 1.0, process_group=None, fused_activations: bool = False):
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.pg = process_group
@@ -84,6 +84,8 @@ class DecoderTrainer:
             from .gaussian_renderer import render_simple
             render_fn = render_simple
         self.render_fn = render_fn
+        # fused_activations: sigmoid / exp / normalize inside the raster kernels (HIP render_simple only)
+        self.render_kwargs = {"fused_activations": True} if fused_activations else {}
         self.bg = torch.tensor([0.55717, 0.52256, 0.51045], dtype=torch.float32, device=self.device)
         self.gaussians = GaussianModel(0)
 
@@ -128,7 +130,7 @@ class DecoderTrainer:
             gs._opacity, gs._features_dc = out.opacity, out.color.unsqueeze(1)
             fov = float(batch.fov_deg[b]) / 360 * 2 * math.pi
             cam = CustomCam(size=self.image_size, fov=fov, extr=batch.cam2world[b])
-            image = self.render_fn(cam, gs, bg_color=self.bg)["render"][:3]
+            image = self.render_fn(cam, gs, bg_color=self.bg, **self.render_kwargs)["render"][:3]
             target = batch.target[b]
             loss = self.l1_weight * torch.abs(image - target).mean() + self.l2_weight * ((image - target) ** 2).mean()
             total = total + loss

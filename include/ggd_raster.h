@@ -62,6 +62,10 @@ typedef struct ggd_params {
   const float* projmatrix;  /* device, 16 floats: full_proj_transform flattened row-major (= (P V)^T), cameras.py:91 */
   const float* campos;      /* device, 3 floats */
   const float* bg;          /* device, 3 floats */
+  int32_t raw_attributes;   /* 1: `scales`, `rotations`, `opacities` are the RAW decoder outputs and the activation
+                               prologue of gaussian_model.py:100-121 (exp / L2-normalise (eps 1e-12) / sigmoid) is fused
+                               into the per-Gaussian kernels, forward and backward; 0: as upstream */
+  int32_t reserved_;
 } ggd_params;
 
 /* One record per Gaussian, written by the preprocess kernel and gathered by the blend kernels. */
@@ -147,6 +151,7 @@ int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* prm,
  */
 int ggd_backward(ggd_ctx* ctx, void* stream, const ggd_params* prm,
                  const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* opacities /* only read when prm->raw_attributes */,
                  const float* scales, const float* rotations, const float* cov3D_precomp,
                  const int32_t* radii,
                  const void* geom_buf, const void* binning_buf, const void* img_buf, int64_t num_rendered,

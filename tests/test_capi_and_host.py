@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(native_lib):
 
 def test_layouts_and_sort_bits(native_lib):
     from gaussian_gan_decoder_amd import _capi
-    assert C.sizeof(_capi.Params) == 72
+    assert C.sizeof(_capi.Params) == 80
     gv = _capi.geom_view(1000)
     assert gv.splat == 0 and gv.tiles_touched >= 48 * 1000 and gv.total == native_lib.ggd_geom_bytes(1000)
     assert gv.point_offsets - gv.tiles_touched >= 4000 and gv.total - gv.clamped >= 1000
