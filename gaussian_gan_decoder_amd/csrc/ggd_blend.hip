@@ -38,7 +38,14 @@ __device__ __forceinline__ TileGeom tile_geom(int gx, const uint32_t* __restrict
   return g;
 }
 
-typedef float f2 __attribute__((ext_vector_type(2)));  // -> v_pk_{add,mul}_f32: two pixels per VALU issue
+typedef float f2 __attribute__((ext_vector_type(2)));  // -> v_pk_{add,mul,fma}_f32: two pixels per VALU issue
+
+// power = -1/2 (A dx^2 + C dy^2) - B dx dy for a pixel PAIR, in the project's fixed operation order (same as the
+// oracle's gauss_power):  fma( fma(-A/2, dx, -B*dy), dx, ((-C/2)*dy)*dy ).  hA = -A/2; nBdy, hCdy2 are per-lane.
+__device__ __forceinline__ f2 gauss_power2(float hA, float nBdy, float hCdy2, f2 dx) {
+  const f2 inner = __builtin_elementwise_fma((f2){hA, hA}, dx, (f2){nBdy, nBdy});
+  return __builtin_elementwise_fma(inner, dx, (f2){hCdy2, hCdy2});
+}
 
 // exp() variants for the blend (GGD_OPT_EXP_MODE).
 template <int MODE>
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
       const float4 b = s_rec[j * 3 + 1];  // conC, opacity, r, g
       const float2 c = *reinterpret_cast<const float2*>(&s_rec[j * 3 + 2]);  // b, power threshold
       const float dy = a.y - pyf;
-      const float cdy2 = b.x * dy * dy;
+      const float hA = -0.5f * a.z, nBdy = (-a.w) * dy, hCdy2 = ((-0.5f * b.x) * dy) * dy;
       const f2 gxx = {a.x, a.x};
       f2 pw[NP];
       bool need[PXL];
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const f2 dx = gxx - px[p];
-        pw[p] = -0.5f * (a.z * dx * dx + cdy2) - a.w * dx * dy;
+        pw[p] = gauss_power2(hA, nBdy, hCdy2, dx);
         need[2 * p] = pw[p].x >= c.y; need[2 * p + 1] = pw[p].y >= c.y;
         lane_need = lane_need || need[2 * p] || need[2 * p + 1];
       }
@@ -308,13 +315,13 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
       const float2 c2 = *reinterpret_cast<const float2*>(&s_rec[j * 3 + 2]);     // b, power threshold
       const float col[3] = {b.z, b.w, c2.x};
       const float dy = a.y - pyf;
-      const float cdy2 = b.x * dy * dy;
+      const float hA = -0.5f * a.z, nBdy = (-a.w) * dy, hCdy2 = ((-0.5f * b.x) * dy) * dy;
       const f2 gxx = {a.x, a.x};
       f2 dx[2], pw[2];
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         dx[p] = gxx - px[p];
-        pw[p] = -0.5f * (a.z * dx[p] * dx[p] + cdy2) - a.w * dx[p] * dy;
+        pw[p] = gauss_power2(hA, nBdy, hCdy2, dx[p]);
       }
       const bool n0 = (pos0 < lastn[0]) && (pw[0].x >= c2.y), n1 = (pos0 < lastn[1]) && (pw[0].y >= c2.y),
                  n2 = (pos0 < lastn[2]) && (pw[1].x >= c2.y), n3 = (pos0 < lastn[3]) && (pw[1].y >= c2.y);

@@ -247,15 +247,14 @@ __global__ __launch_bounds__(TB_THREADS) void tilebin_scatter_kernel(
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   uint16_t* mycnt = cnt + (size_t)wv * T;
 
-  // sweep 1: per-wave tile counts
-  tb_for_rounds(sh, wbeg, wend, gx, [&](bool ok, uint32_t tile, uint32_t) {
-    uint64_t peers = __ballot(ok);
-    for (int b = 0; b < tbits; ++b) {
-      const uint64_t m = __ballot((tile >> b) & 1u);
-      peers &= ((tile >> b) & 1u) ? m : ~m;
-    }
-    if (ok && (peers & lt_mask) == 0ull) mycnt[tile] = (uint16_t)(mycnt[tile] + (uint32_t)__popcll(peers));
-  });
+  // sweep 1: per-wave tile counts -- order does not matter for counting, so one LDS atomic per instance on the
+  // 32-bit word that holds the tile's 16-bit counter (counts <= 1024 never carry into the neighbour)
+  {
+    uint32_t* mycnt32 = reinterpret_cast<uint32_t*>(mycnt);
+    tb_for_rounds(sh, wbeg, wend, gx, [&](bool ok, uint32_t tile, uint32_t) {
+      if (ok) atomicAdd(&mycnt32[tile >> 1], 1u << (16u * (tile & 1u)));
+    });
+  }
   __syncthreads();
   {
     const uint32_t* row = prefix + (size_t)blockIdx.x * T;

@@ -28,12 +28,14 @@ typedef struct ggo_params {
 #define R_SQRT sqrtf
 #define R_CEIL ceilf
 #define R_EXP expf
+#define R_FMA fmaf
 #include "ggd_oracle_impl.inc"
 #undef REAL
 #undef SUF
 #undef R_SQRT
 #undef R_CEIL
 #undef R_EXP
+#undef R_FMA
 #undef SH_C0
 #undef SH_C1
 
@@ -42,6 +44,7 @@ typedef struct ggo_params {
 #define R_SQRT sqrt
 #define R_CEIL ceil
 #define R_EXP exp
+#define R_FMA fma
 #include "ggd_oracle_impl.inc"
 #undef REAL
 #undef SUF
