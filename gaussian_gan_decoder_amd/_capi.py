@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_PKG, "libggd_raster.so")
 EXPORTS = [
     "ggd_geom_bytes", "ggd_binning_bytes", "ggd_img_bytes", "ggd_geom_layout", "ggd_binning_layout",
     "ggd_img_layout", "ggd_sort_bits", "ggd_create", "ggd_destroy", "ggd_last_error", "ggd_version",
-    "ggd_forward_geometry", "ggd_forward_render", "ggd_backward", "ggd_mark_visible", "ggd_debug_unsorted",
+    "ggd_forward_geometry", "ggd_forward_render", "ggd_forward", "ggd_forward_can_speculate", "ggd_backward", "ggd_mark_visible", "ggd_debug_unsorted",
     "ggd_triplane_forward", "ggd_triplane_backward", "ggd_decoder_packed_bytes", "ggd_decoder_forward", "ggd_set_option", "ggd_get_option", "ggd_blend_stats", "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
 ]
 
@@ -75,6 +75,8 @@ def load():
         lib.ggd_version.restype = C.c_char_p
         lib.ggd_forward_geometry.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 7 + [vp, vp, C.POINTER(i64)]
         lib.ggd_forward_render.argtypes = [vp, vp, C.POINTER(Params), vp, i64, vp, vp, vp]
+        lib.ggd_forward.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 7 + [vp, vp, vp, i64, vp, vp, C.POINTER(i64)]
+        lib.ggd_forward_can_speculate.argtypes = [vp, C.POINTER(Params), i64]
         lib.ggd_backward.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 7 + [vp, vp, vp, vp, i64, vp] + [vp] * 8
         lib.ggd_mark_visible.argtypes = [vp, vp, i32, vp, vp, vp, vp]
         lib.ggd_debug_unsorted.argtypes = [vp, vp, vp, vp, i64]
@@ -98,8 +100,10 @@ class RasterError(RuntimeError):
 
 class Context:
     """One ggd_ctx (device workspace); not re-entrant, use one per (device, stream)."""
+    capacity_hint: dict  # (P, W, H) -> last num_rendered: sizes the binning buffer of the next single-call forward
 
     def __init__(self, device_index: int):
+        self.capacity_hint = {}
         self.lib = load()
         self.device_index = int(device_index)
         self.handle = self.lib.ggd_create(self.device_index)

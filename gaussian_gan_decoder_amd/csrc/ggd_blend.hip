@@ -70,7 +70,7 @@ template <int PXL>
 struct WaveGeom {
   int px0, py;
   uint32_t lo, hi;
-  __device__ __forceinline__ WaveGeom(int gx, int T, const uint32_t* __restrict__ ranges) {
+  __device__ __forceinline__ WaveGeom(int gx, int T, const uint32_t* __restrict__ ranges, uint32_t capacity = 0xffffffffu) {
     constexpr int LPR = 16 / PXL, ROWS = 64 / LPR;
     const int tile = (int)blockIdx.x % T, sub = (int)blockIdx.x / T;
     const int tx = tile % gx, ty = tile / gx;
@@ -78,7 +78,7 @@ struct WaveGeom {
     px0 = tx * 16 + (lane % LPR) * PXL;
     py = ty * 16 + sub * ROWS + lane / LPR;
     const uint2 r = reinterpret_cast<const uint2*>(ranges)[tile];
-    lo = r.x; hi = r.y;
+    lo = min(r.x, capacity); hi = min(r.y, capacity);  // capacity < R only in a speculative forward that is retried
   }
 };
 
@@ -93,7 +93,7 @@ template <int EXP_MODE, bool CULL, int PXL>
 __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx, int T,
                                                            const ggd_splat* __restrict__ splat,
                                                            const uint32_t* __restrict__ list,
-                                                           const uint32_t* __restrict__ ranges,
+                                                           const uint32_t* __restrict__ ranges, uint32_t capacity,
                                                            const float* __restrict__ bg,
                                                            float* __restrict__ out_color,
                                                            float* __restrict__ final_T,
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
   constexpr int NP = PXL / 2;  // pixel pairs per lane
   __shared__ float4 s_rec[64 * 3];
   const int lane = threadIdx.x;
-  const WaveGeom<PXL> g(gx, T, ranges);
+  const WaveGeom<PXL> g(gx, T, ranges, capacity);
   const bool row_in = g.py < H;
   const float INF = __builtin_huge_valf();
   uint32_t st_visited = 0, st_culled = 0, st_lanes = 0, st_pixels = 0;  // wave-uniform debug counters (GGD stats)
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
 }  // namespace
 
 int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
-                     const uint32_t* list, const uint32_t* ranges, float* out_color, float* final_T,
+                     const uint32_t* list, const uint32_t* ranges, uint32_t capacity, float* out_color, float* final_T,
                      uint32_t* n_contrib) {
   const int gx = (prm.width + 15) / 16, gy = (prm.height + 15) / 16;
   if (gx * gy == 0) return GGD_OK;
@@ -423,10 +423,10 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
   do {                                                                                                              \
     if (two)                                                                                                        \
       hipLaunchKernelGGL((blend_forward_kernel<EM, CU, 2>), dim3(2 * T), dim3(64), 0, s, prm.width, prm.height, gx, \
-                         T, splat, list, ranges, prm.bg, out_color, final_T, n_contrib, ctx->blend_stats);         \
+                         T, splat, list, ranges, capacity, prm.bg, out_color, final_T, n_contrib, ctx->blend_stats); \
     else                                                                                                            \
       hipLaunchKernelGGL((blend_forward_kernel<EM, CU, 4>), dim3(T), dim3(64), 0, s, prm.width, prm.height, gx, T,  \
-                         splat, list, ranges, prm.bg, out_color, final_T, n_contrib, ctx->blend_stats);            \
+                         splat, list, ranges, capacity, prm.bg, out_color, final_T, n_contrib, ctx->blend_stats);  \
   } while (0)
   if (cull) {
     if (em == 0) GGD_LAUNCH_FWD(0, true); else if (em == 1) GGD_LAUNCH_FWD(1, true); else GGD_LAUNCH_FWD(2, true);

@@ -211,10 +211,11 @@ static int check_inputs(ggd_ctx* ctx, const ggd_params* prm, const float* means3
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------
-extern "C" int ggd_forward_geometry(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D,
-                                    const float* shs, const float* colors_precomp, const float* opacities,
-                                    const float* scales, const float* rotations, const float* cov3D_precomp,
-                                    void* geom_buf, int32_t* radii, int64_t* num_rendered) {
+// Enqueue the per-Gaussian kernels + scan + the asynchronous read-back of {R, prefilter trap}; no host sync.
+static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D,
+                            const float* shs, const float* colors_precomp, const float* opacities,
+                            const float* scales, const float* rotations, const float* cov3D_precomp,
+                            void* geom_buf, int32_t* radii, int64_t* num_rendered) {
   int rc = check_params(ctx, prm);
   if (rc != GGD_OK) return rc;
   rc = check_inputs(ctx, prm, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp);
@@ -257,15 +258,34 @@ extern "C" int ggd_forward_geometry(ggd_ctx* ctx, void* stream, const ggd_params
     StageTimer t(ctx, ST_READBACK, s);
     GGD_HIP(hipMemcpyAsync(ctx->h_words, ctx->d_words, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   }
-  GGD_HIP(hipStreamSynchronize(s));
+  return GGD_OK;
+}
+
+// Wait for the stream and publish R (the one host sync of a forward).
+static int geometry_finish(ggd_ctx* ctx, void* stream, const ggd_params* prm, int64_t* num_rendered) {
+  GGD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   if (prm->prefiltered && ctx->h_words[1] != 0)
     return ggd_fail(ctx, GGD_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
   *num_rendered = (int64_t)ctx->h_words[0];
   return GGD_OK;
 }
 
-extern "C" int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* prm, const void* geom_buf,
-                                  int64_t R, void* binning_buf, void* img_buf, float* out_color) {
+extern "C" int ggd_forward_geometry(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D,
+                                    const float* shs, const float* colors_precomp, const float* opacities,
+                                    const float* scales, const float* rotations, const float* cov3D_precomp,
+                                    void* geom_buf, int32_t* radii, int64_t* num_rendered) {
+  const int rc = geometry_enqueue(ctx, stream, prm, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                  cov3D_precomp, geom_buf, radii, num_rendered);
+  if (rc != GGD_OK || prm->P == 0) return rc;
+  return geometry_finish(ctx, stream, prm, num_rendered);
+}
+
+// R = the value binning_buf was laid out for.  speculative: R is only a CAPACITY (the true num_rendered is still on
+// the device); only the tile-binning path can run that way (its launch geometry does not depend on R).
+static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, const void* geom_buf, int64_t layout_R,
+                          int64_t R, void* binning_buf, void* img_buf, float* out_color, bool speculative) {
+  // layout_R: what binning_buf was laid out for; R: number of instances to process (== layout_R unless the caller
+  // over-allocated; in the speculative case the true count is still on the device and R is only its upper bound)
   int rc = check_params(ctx, prm);
   if (rc != GGD_OK) return rc;
   if (R < 0) return ggd_fail(ctx, GGD_E_INVALID, "num_rendered < 0");
@@ -273,7 +293,7 @@ extern "C" int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* 
   if (R > 0 && (!geom_buf || !binning_buf)) return ggd_fail(ctx, GGD_E_INVALID, "geom_buf / binning_buf is NULL");
   hipStream_t s = static_cast<hipStream_t>(stream);
   ggd_geom_view gv; ggd_binning_view bv; ggd_img_view iv;
-  ggd_geom_layout(prm->P, &gv); ggd_binning_layout(R, &bv); ggd_img_layout(prm->width, prm->height, &iv);
+  ggd_geom_layout(prm->P, &gv); ggd_binning_layout(layout_R, &bv); ggd_img_layout(prm->width, prm->height, &iv);
   const char* gb = static_cast<const char*>(geom_buf);
   char* bb = static_cast<char*>(binning_buf);
   char* ib = static_cast<char*>(img_buf);
@@ -292,6 +312,8 @@ extern "C" int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* 
 
   const int bmode = ctx->opt[GGD_OPT_BINNING];
   const bool tilebin = (bmode == 2 || (bmode == 1 && R >= (1 << 20))) && !prm->debug && ggd_tilebin_supported(T);
+  if (speculative && !tilebin) return ggd_fail(ctx, GGD_E_INVALID, "speculative render needs the tile-binning path");
+  const uint32_t capacity = R > 0xffffffffll ? 0xffffffffu : (uint32_t)R;
   if (R > 0 && tilebin) {
     // depth-sort the Gaussians once (32-bit keys), then one stable tile-binning pass
     const uint32_t* depth_keys = reinterpret_cast<const uint32_t*>(gb + gv.depth_keys);
@@ -316,7 +338,7 @@ extern "C" int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* 
       StageTimer t(ctx, ST_DUPLICATE, s);
       // culled Gaussians carry the key 0xFFFFFFFF: their count is bin 255 of the top-digit histogram of the depth sort
       const uint32_t* culled = static_cast<const uint32_t*>(tmp) + 3 * 256 + 255;
-      rc = ggd_launch_tilebin(ctx, s, *prm, splat, tiles, va, culled, list, ranges, bin_tmp_ptr, bin_tmp);
+      rc = ggd_launch_tilebin(ctx, s, *prm, splat, tiles, va, culled, list, ranges, capacity, bin_tmp_ptr, bin_tmp);
       if (rc != GGD_OK) return rc;
     }
   } else {
@@ -358,10 +380,49 @@ extern "C" int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* 
   }
   {
     StageTimer t(ctx, ST_BLEND, s);
-    rc = ggd_launch_blend(ctx, s, *prm, splat, list, ranges, out_color, final_T, n_contrib);
+    rc = ggd_launch_blend(ctx, s, *prm, splat, list, ranges, capacity, out_color, final_T, n_contrib);
     if (rc != GGD_OK) return rc;
   }
   return GGD_OK;
+}
+
+extern "C" int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* prm, const void* geom_buf,
+                                  int64_t R, void* binning_buf, void* img_buf, float* out_color) {
+  return render_enqueue(ctx, stream, prm, geom_buf, R, R, binning_buf, img_buf, out_color, false);
+}
+
+extern "C" int ggd_forward_can_speculate(ggd_ctx* ctx, const ggd_params* prm, int64_t capacity) {
+  if (!ctx || !prm || prm->debug || prm->P <= 0) return 0;
+  const int T = ((prm->width + 15) / 16) * ((prm->height + 15) / 16);
+  const int bmode = ctx->opt[GGD_OPT_BINNING];
+  return ((bmode == 2 || (bmode == 1 && capacity >= (1 << 20))) && ggd_tilebin_supported(T)) ? 1 : 0;
+}
+
+extern "C" int ggd_forward(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, void* geom_buf, int32_t* radii,
+                           void* binning_buf, int64_t capacity, void* img_buf, float* out_color,
+                           int64_t* num_rendered) {
+  if (capacity < 0) return ggd_fail(ctx, GGD_E_INVALID, "capacity < 0");
+  int rc = geometry_enqueue(ctx, stream, prm, means3D, shs, colors_precomp, opacities, scales, rotations,
+                            cov3D_precomp, geom_buf, radii, num_rendered);
+  if (rc != GGD_OK) return rc;
+  if (prm->P == 0) return render_enqueue(ctx, stream, prm, geom_buf, capacity, 0, binning_buf, img_buf, out_color, false);
+  if (ggd_forward_can_speculate(ctx, prm, capacity)) {
+    // everything is enqueued before the host waits: the GPU never idles on the num_rendered read-back
+    rc = render_enqueue(ctx, stream, prm, geom_buf, capacity, capacity, binning_buf, img_buf, out_color, true);
+    if (rc != GGD_OK) return rc;
+    rc = geometry_finish(ctx, stream, prm, num_rendered);
+    if (rc != GGD_OK) return rc;
+    if (*num_rendered > capacity)
+      return ggd_fail(ctx, GGD_E_CAPACITY, "binning_buf capacity is below num_rendered: re-run with a larger buffer");
+    return GGD_OK;
+  }
+  rc = geometry_finish(ctx, stream, prm, num_rendered);
+  if (rc != GGD_OK) return rc;
+  if (*num_rendered > capacity)
+    return ggd_fail(ctx, GGD_E_CAPACITY, "binning_buf capacity is below num_rendered: re-run with a larger buffer");
+  return render_enqueue(ctx, stream, prm, geom_buf, capacity, *num_rendered, binning_buf, img_buf, out_color, false);
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------

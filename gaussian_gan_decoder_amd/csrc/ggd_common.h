@@ -89,10 +89,10 @@ bool ggd_tilebin_supported(int T);
 size_t ggd_tilebin_tmp_bytes(int P, int T);
 int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
                        const uint32_t* tiles_touched, const uint32_t* order, const uint32_t* culled_count,
-                       uint32_t* list, uint32_t* ranges, void* tmp, size_t tmp_bytes);
+                       uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp, size_t tmp_bytes);
 int ggd_launch_ranges(ggd_ctx* ctx, hipStream_t s, const uint64_t* keys, int64_t n, uint32_t* ranges, int T);
 int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
-                     const uint32_t* list, const uint32_t* ranges, float* out_color, float* final_T,
+                     const uint32_t* list, const uint32_t* ranges, uint32_t capacity, float* out_color, float* final_T,
                      uint32_t* n_contrib);
 int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
                               const uint32_t* list, const uint32_t* ranges, const float* final_T,

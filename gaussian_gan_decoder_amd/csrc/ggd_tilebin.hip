@@ -203,7 +203,7 @@ __global__ __launch_bounds__(TB_THREADS) void tilebin_scatter_kernel(
     int W, int H, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ order, const uint32_t* __restrict__ culled_count, int P,
     const uint32_t* __restrict__ prefix /*[nb][T]*/, const uint32_t* __restrict__ totals, int T, int tbits,
-    uint32_t* __restrict__ list, uint32_t* __restrict__ ranges) {
+    uint32_t* __restrict__ list, uint32_t* __restrict__ ranges, uint32_t capacity) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TbPool& sh = *reinterpret_cast<TbPool*>(smem);
   uint32_t* base = reinterpret_cast<uint32_t*>(smem + sizeof(TbPool));           // [T]
@@ -278,7 +278,8 @@ __global__ __launch_bounds__(TB_THREADS) void tilebin_scatter_kernel(
     if (ok) before = mycnt[tile];
     __builtin_amdgcn_wave_barrier();
     if (ok) {
-      list[(size_t)base[tile] + before + below] = id;
+      const uint32_t dst = base[tile] + before + below;
+      if (dst < capacity) list[dst] = id;  // capacity < R only in the speculative single-call forward (then retried)
       if (below == 0) mycnt[tile] = (uint16_t)(before + (uint32_t)__popcll(peers));
     }
   });
@@ -296,7 +297,7 @@ size_t ggd_tilebin_tmp_bytes(int P, int T) {
 
 int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
                        const uint32_t* tiles_touched, const uint32_t* order, const uint32_t* culled_count,
-                       uint32_t* list, uint32_t* ranges, void* tmp, size_t tmp_bytes) {
+                       uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp, size_t tmp_bytes) {
   const int T = ((prm.width + 15) / 16) * ((prm.height + 15) / 16);
   if (!ggd_tilebin_supported(T)) return ggd_fail(ctx, GGD_E_INVALID, "tile grid too large for the binning path");
   if (tmp_bytes < ggd_tilebin_tmp_bytes(prm.P, T)) return ggd_fail(ctx, GGD_E_INVALID, "tilebin tmp too small");
@@ -319,7 +320,7 @@ int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const
                      tiles_touched, order, culled_count, prm.P, counts, T);
   hipLaunchKernelGGL(tilebin_scan_kernel, dim3((T + 63) / 64), dim3(64 * TS_WAVES), 0, s, counts, T, culled_count, prm.P, totals);
   hipLaunchKernelGGL(tilebin_scatter_kernel, dim3(nb), dim3(TB_THREADS), lds_scatter, s, prm.width, prm.height, splat,
-                     tiles_touched, order, culled_count, prm.P, counts, totals, T, tbits, list, ranges);
+                     tiles_touched, order, culled_count, prm.P, counts, totals, T, tbits, list, ranges, capacity);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }

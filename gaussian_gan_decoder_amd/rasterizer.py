@@ -89,7 +89,9 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
                                cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
                                sh, degree, campos, prefiltered, debug, raw_attributes=False):
     """== upstream `_C.rasterize_gaussians(...)`: returns
-    (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer)."""
+    (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer).
+    `rasterize_gaussians_native.last_layout_R` is the value binningBuffer was laid out for (== num_rendered on the
+    two-phase path, the capacity on the single-call path); pass it as R to the backward."""
     _require_cuda(means3D)
     dev = means3D.device
     if means3D.dim() != 2 or means3D.size(1) != 3:
@@ -122,13 +124,34 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
     img = torch.empty((lib.ggd_img_bytes(W, H),), **u8)
     R = C.c_int64(0)
     stream = _stream(dev)
+    key = (P, W, H)
+    hint = ctx.capacity_hint.get(key)
     with torch.cuda.device(dev):
-        ctx.check(lib.ggd_forward_geometry(ctx.handle, stream, C.byref(prm), _ptr(means3D), _ptr(sh_c), _ptr(col_c),
-                                           _ptr(opacities), _ptr(sc_c), _ptr(rot_c), _ptr(cov_c), _ptr(geom),
-                                           _ptr(radii), C.byref(R)))
-        binning = torch.empty((lib.ggd_binning_bytes(R.value),), **u8)
-        ctx.check(lib.ggd_forward_render(ctx.handle, stream, C.byref(prm), _ptr(geom), R.value, _ptr(binning),
-                                         _ptr(img), _ptr(color)))
+        binning = None
+        if hint is not None and P > 0:
+            # single-call forward: binning buffer sized from the previous frame of this shape (+25 %); the GPU does
+            # not wait for the num_rendered round trip.  Falls through to the exact two-phase path on overflow.
+            cap = int(hint * 1.25) + 65536
+            binning = torch.empty((lib.ggd_binning_bytes(cap),), **u8)
+            rc = lib.ggd_forward(ctx.handle, stream, C.byref(prm), _ptr(means3D), _ptr(sh_c), _ptr(col_c),
+                                 _ptr(opacities), _ptr(sc_c), _ptr(rot_c), _ptr(cov_c), _ptr(geom), _ptr(radii),
+                                 _ptr(binning), cap, _ptr(img), _ptr(color), C.byref(R))
+            if rc == -6:       # GGD_E_CAPACITY: R is valid, redo the render phase with an exact buffer
+                binning = None
+            else:
+                ctx.check(rc)
+                layout_R = cap
+        else:
+            ctx.check(lib.ggd_forward_geometry(ctx.handle, stream, C.byref(prm), _ptr(means3D), _ptr(sh_c),
+                                               _ptr(col_c), _ptr(opacities), _ptr(sc_c), _ptr(rot_c), _ptr(cov_c),
+                                               _ptr(geom), _ptr(radii), C.byref(R)))
+        if binning is None:
+            binning = torch.empty((lib.ggd_binning_bytes(R.value),), **u8)
+            ctx.check(lib.ggd_forward_render(ctx.handle, stream, C.byref(prm), _ptr(geom), R.value, _ptr(binning),
+                                             _ptr(img), _ptr(color)))
+            layout_R = int(R.value)
+    ctx.capacity_hint[key] = int(R.value)
+    rasterize_gaussians_native.last_layout_R = layout_R
     return int(R.value), color, radii, geom, binning, img
 
 
@@ -202,7 +225,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
             rs.campos, rs.prefiltered, rs.debug, getattr(rs, "raw_attributes", False))
         ctx.raster_settings = rs
-        ctx.num_rendered = num_rendered
+        ctx.num_rendered = rasterize_gaussians_native.last_layout_R   # what binningBuffer was laid out for
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning,
                               img, opacities)
         ctx.mark_non_differentiable(radii)

@@ -42,7 +42,8 @@ enum {
   GGD_E_HIP = -2,       /* a HIP runtime call failed */
   GGD_E_NOMEM = -3,     /* workspace allocation failed */
   GGD_E_PREFILTER = -4, /* prefiltered=1 but a Gaussian failed the frustum test (upstream traps here) */
-  GGD_E_NODEVICE = -5   /* no gfx950 device visible */
+  GGD_E_NODEVICE = -5,  /* no gfx950 device visible */
+  GGD_E_CAPACITY = -6   /* ggd_forward: binning_buf capacity below num_rendered (num_rendered is valid: retry) */
 };
 
 typedef struct ggd_ctx ggd_ctx;
@@ -141,6 +142,21 @@ int ggd_forward_geometry(ggd_ctx* ctx, void* stream, const ggd_params* prm,
 int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* prm,
                        const void* geom_buf, int64_t num_rendered,
                        void* binning_buf, void* img_buf, float* out_color);
+
+/*
+ * Forward in ONE call with a caller-chosen binning capacity (instances): geometry + render are enqueued back to back
+ * and the host waits once at the end, so the GPU does not idle while num_rendered travels to the host (the two-phase
+ * form above stalls the stream for that round trip).  binning_buf must hold ggd_binning_bytes(capacity).  Returns
+ * GGD_E_CAPACITY (with *num_rendered set) when capacity < num_rendered: call again with a larger buffer.  The same
+ * `capacity` must be passed as `num_rendered` to ggd_backward (it lays out binning_buf).  ggd_forward_can_speculate
+ * tells whether the call will take the speculative route (tile-binning path) for that capacity.
+ */
+int ggd_forward(ggd_ctx* ctx, void* stream, const ggd_params* prm,
+                const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                const float* scales, const float* rotations, const float* cov3D_precomp,
+                void* geom_buf, int32_t* radii, void* binning_buf, int64_t capacity, void* img_buf,
+                float* out_color, int64_t* num_rendered);
+int ggd_forward_can_speculate(ggd_ctx* ctx, const ggd_params* prm, int64_t capacity);
 
 /*
  * Backward.  Consumes the three buffers of the matching forward plus the original inputs and dL/d(out_color).

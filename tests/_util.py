@@ -61,8 +61,9 @@ def run_native(d, device="cuda:0", debug=True, binning=None):
         t(d["bg"]), t(d["means3D"]), t(d["colors_precomp"]), t(d["opacities"]), t(d["scales"]), t(d["rotations"]),
         d["scale_modifier"], t(d["cov3D_precomp"]), t(d["viewmatrix"]), t(d["projmatrix"]), d["tanfovx"],
         d["tanfovy"], d["H"], d["W"], t(d["shs"]), d["sh_degree"], t(d["campos"]), False, debug)
-    out = dict(num_rendered=num_rendered, color=color, radii=radii, geom=geom, binning=binning, img=img)
-    out.update(decode_buffers(d["P"], d["W"], d["H"], num_rendered, geom, binning, img))
+    layout_R = R.rasterize_gaussians_native.last_layout_R   # what `binning` was laid out for (>= num_rendered)
+    out = dict(num_rendered=num_rendered, layout_R=layout_R, color=color, radii=radii, geom=geom, binning=binning, img=img)
+    out.update(decode_buffers(d["P"], d["W"], d["H"], num_rendered, geom, binning, img, layout_R))
     if debug and num_rendered > 0:
         ctx = _capi.context_for(dev)
         ku = torch.empty(num_rendered, dtype=torch.int64, device=dev)
@@ -76,9 +77,9 @@ def run_native(d, device="cuda:0", debug=True, binning=None):
     return out
 
 
-def decode_buffers(P, W, H, R, geom, binning, img):
+def decode_buffers(P, W, H, R, geom, binning, img, layout_R=None):
     from gaussian_gan_decoder_amd import _capi
-    gv, bv, iv = _capi.geom_view(P), _capi.binning_view(R), _capi.img_view(W, H)
+    gv, bv, iv = _capi.geom_view(P), _capi.binning_view(R if layout_R is None else layout_R), _capi.img_view(W, H)
     g = geom.cpu().numpy(); b = binning.cpu().numpy(); im = img.cpu().numpy()
     T = ((W + 15) // 16) * ((H + 15) // 16)
     splat = g[gv.splat:gv.splat + 48 * P].view(np.float32).reshape(P, 12)
@@ -103,7 +104,7 @@ def run_native_backward(d, n, dL_dpix, device="cuda:0"):
     outs = R.rasterize_gaussians_backward_native(
         t(d["bg"]), t(d["means3D"]), n["radii"], t(d["colors_precomp"]), t(d["scales"]), t(d["rotations"]),
         d["scale_modifier"], t(d["cov3D_precomp"]), t(d["viewmatrix"]), t(d["projmatrix"]), d["tanfovx"],
-        d["tanfovy"], dL_dpix.to(dev), t(d["shs"]), d["sh_degree"], t(d["campos"]), n["geom"], n["num_rendered"],
+        d["tanfovy"], dL_dpix.to(dev), t(d["shs"]), d["sh_degree"], t(d["campos"]), n["geom"], n["layout_R"],
         n["binning"], n["img"], False)
     names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
              "dL_drots")
