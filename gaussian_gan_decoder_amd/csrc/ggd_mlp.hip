@@ -110,13 +110,34 @@ __device__ __forceinline__ void gelu_pack(const f4 (&acc)[2][8], bf16x8 (&bout)[
     }
 }
 
+// D-layout tile set (8 feature tiles x 2 point tiles, fp32) <-> row-major bf16 [point][128]: lane (j = point, g) holds
+// features 16*mt + 4g + r, i.e. 4 consecutive bf16 (8 bytes) of the point's row.
+__device__ __forceinline__ void store_z(__bf16* __restrict__ zl, const f4 (&acc)[2][8], int64_t p0, int64_t cend,
+                                        int lane) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int64_t pt = p0 + 16 * c + j;
+    if (pt >= cend) continue;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      bf16x4 v;
+      v[0] = (__bf16)acc[c][mt][0]; v[1] = (__bf16)acc[c][mt][1]; v[2] = (__bf16)acc[c][mt][2]; v[3] = (__bf16)acc[c][mt][3];
+      *reinterpret_cast<bf16x4*>(zl + pt * HID + 16 * mt + 4 * g) = v;
+    }
+  }
+}
+
 // attrs row (16 floats per point): [0..2] color, [3] opacity, [4..7] rotation, [8..10] activated scale,
 // [11..13] xyz, [14..15] unused.  It doubles as the carrier of the earlier heads' outputs between heads: the "info"
 // vector a head sees is [position(3), attrs[0 .. n_extra)] with n_extra = 0, 3, 4, 8, 11.
+// STORE_Z (training): the fp32 pre-activations of the three hidden layers are kept (rounded to bf16) for the backward,
+// zbuf[head][layer][point][128], row-major so the weight-gradient GEMMs can read them as plain [N,128] matrices.
+template <bool STORE_Z>
 __global__ __launch_bounds__(MLP_THREADS, 2) void decoder_forward_kernel(const float* __restrict__ feat,
                                                                          const float* __restrict__ pos, int N,
                                                                          const unsigned char* __restrict__ packed,
-                                                                         float* attrs) {
+                                                                         float* attrs, __bf16* __restrict__ zbuf) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* wl = smem;  // HEAD_BYTES: weights + biases of one head
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -170,10 +191,13 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void decoder_forward_kernel(const f
       f4 acc[2][8];
       bf16x8 bh[2][4];
       layer_mfma<2, ROW1>(wl + OFF_W1, b1, bin, acc, lane);
+      if (STORE_Z) store_z(zbuf + ((size_t)(head * 3 + 0) * N) * HID, acc, p0, cend, lane);
       gelu_pack(acc, bh);
       layer_mfma<4, ROW2>(wl + OFF_W2, b2, bh, acc, lane);
+      if (STORE_Z) store_z(zbuf + ((size_t)(head * 3 + 1) * N) * HID, acc, p0, cend, lane);
       gelu_pack(acc, bh);
       layer_mfma<4, ROW2>(wl + OFF_W3, b3, bh, acc, lane);
+      if (STORE_Z) store_z(zbuf + ((size_t)(head * 3 + 2) * N) * HID, acc, p0, cend, lane);
       gelu_pack(acc, bh);
       // ---- output layer: one feature tile (weight rows >= out_dim are zero)
       f4 out[2];
@@ -220,12 +244,14 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void decoder_forward_kernel(const f
   }
 }
 
+#include "ggd_mlp_bwd.inc"
+
 }  // namespace
 
 extern "C" size_t ggd_decoder_packed_bytes(void) { return (size_t)NHEAD * HEAD_BYTES; }
 
-extern "C" int ggd_decoder_forward(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
-                                   const void* packed_weights, float* attrs) {
+static int decoder_forward_impl(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
+                                const void* packed_weights, float* attrs, void* zbuf) {
   if (!ctx) return GGD_E_INVALID;
   if (N < 0) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_forward: N < 0");
   if (N == 0) return GGD_OK;
@@ -233,15 +259,59 @@ extern "C" int ggd_decoder_forward(ggd_ctx* ctx, void* stream, const float* feat
   const size_t lds = HEAD_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_forward_kernel),
+    GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_forward_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_forward_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   int grid = (N + MLP_WAVES * SLAB - 1) / (MLP_WAVES * SLAB);  // at least one slab per wave
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(decoder_forward_kernel, dim3(grid), dim3(MLP_THREADS), lds, static_cast<hipStream_t>(stream), feat,
-                     pos, N, static_cast<const unsigned char*>(packed_weights), attrs);
+  if (zbuf)
+    hipLaunchKernelGGL(decoder_forward_kernel<true>, dim3(grid), dim3(MLP_THREADS), lds, static_cast<hipStream_t>(stream),
+                       feat, pos, N, static_cast<const unsigned char*>(packed_weights), attrs, static_cast<__bf16*>(zbuf));
+  else
+    hipLaunchKernelGGL(decoder_forward_kernel<false>, dim3(grid), dim3(MLP_THREADS), lds, static_cast<hipStream_t>(stream),
+                       feat, pos, N, static_cast<const unsigned char*>(packed_weights), attrs, (__bf16*)nullptr);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
+}
+
+extern "C" int ggd_decoder_forward(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
+                                   const void* packed_weights, float* attrs) {
+  return decoder_forward_impl(ctx, stream, feat, pos, N, packed_weights, attrs, nullptr);
+}
+
+extern "C" size_t ggd_decoder_packed_t_bytes(void) { return (size_t)NHEAD * HEADT_BYTES; }
+
+extern "C" int ggd_decoder_backward(ggd_ctx* ctx, void* stream, int32_t N, const void* packed_t, const float* attrs,
+                                    const float* dattrs, const void* zbuf, void* dzbuf, float* dout, float* dfeat,
+                                    float* dinfo) {
+  if (!ctx) return GGD_E_INVALID;
+  if (N < 0) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_backward: N < 0");
+  if (N == 0) return GGD_OK;
+  if (!packed_t || !attrs || !dattrs || !zbuf || !dzbuf || !dout || !dfeat || !dinfo)
+    return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_backward: NULL pointer");
+  static bool attr_set = false;
+  if (!attr_set) {
+    GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_backward_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEADT_BYTES));
+    attr_set = true;
+  }
+  int grid = (N + MLP_WAVES * SLAB - 1) / (MLP_WAVES * SLAB);
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(decoder_backward_kernel, dim3(grid), dim3(MLP_THREADS), HEADT_BYTES, static_cast<hipStream_t>(stream),
+                     N, static_cast<const unsigned char*>(packed_t), attrs, dattrs, static_cast<const __bf16*>(zbuf),
+                     static_cast<__bf16*>(dzbuf), dout, dfeat, dinfo);
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
+extern "C" size_t ggd_decoder_zbuf_bytes(int32_t N) { return (size_t)NHEAD * 3 * (size_t)(N > 0 ? N : 0) * HID * 2; }
+
+extern "C" int ggd_decoder_forward_train(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
+                                         const void* packed_weights, float* attrs, void* zbuf) {
+  if (ctx && N > 0 && !zbuf) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_forward_train: zbuf is NULL");
+  return decoder_forward_impl(ctx, stream, feat, pos, N, packed_weights, attrs, zbuf);
 }

@@ -58,6 +58,128 @@ def pack_weights(decoder: SequentialDecoderReverse) -> torch.Tensor:
     return packed
 
 
+_HEADS = ("color_decoder", "opacity_decoder", "rotation_decoder", "scale_decoder", "xyz_decoder")
+_N_EXTRA = (0, 3, 4, 8, 11)   # chained inputs of each head (outputs of the earlier heads)
+_OUT_DIM = (3, 1, 4, 3, 3)
+ROW4T = 32 + 8
+
+
+def _head_tensors(decoder):
+    """[(W1,b1,W2,b2,W3,b3,W4,b4)] * 5 in head order."""
+    out = []
+    for name in _HEADS:
+        bb = getattr(decoder, name).backbone
+        out.append(tuple(t for k in (0, 2, 4, 6) for t in (bb[k].weight, bb[k].bias)))
+    return out
+
+
+def pack_weights_t(decoder: SequentialDecoderReverse) -> torch.Tensor:
+    """Transposed weight image for ggd_decoder_backward: per head [W4^T 128x40 | W3^T 128x136 | W2^T 128x136 |
+    W1^T 64x136] bf16, every row's K (= the layer's OUTPUT features) permuted like the forward image."""
+    dev = next(decoder.parameters()).device
+    chunks = []
+    for (w1, _, w2, _, w3, _, w4, _) in _head_tensors(decoder):
+        w1f = torch.zeros(HID, 64, device=dev); w1f[:, :w1.shape[1]] = w1.detach().float()
+        w4f = torch.zeros(32, HID, device=dev); w4f[:w4.shape[0]] = w4.detach().float()
+        for wt, row in ((w4f.t(), ROW4T), (w3.detach().float().t(), ROW2), (w2.detach().float().t(), ROW2),
+                        (w1f.t(), ROW2)):
+            wp = torch.zeros(wt.shape[0], row, device=dev)
+            wp[:, :wt.shape[1]] = _permute_blocks(wt.contiguous())
+            chunks.append(wp.to(torch.bfloat16).contiguous().view(torch.uint8).reshape(-1))
+    packed = torch.cat(chunks).contiguous()
+    expect = _capi.load().ggd_decoder_packed_t_bytes()
+    if packed.numel() != expect:
+        raise RuntimeError(f"packed transposed image is {packed.numel()} bytes, library expects {expect}")
+    return packed
+
+
+def _splitk_dw(dy: torch.Tensor, x: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
+    """dW = dy^T x over N points ([N,out], [N,in] bf16) as a batched split-K product (keeps all CUs busy)."""
+    n = dy.shape[0]
+    main = (n // chunk) * chunk
+    dw = None
+    if main:
+        dw = torch.bmm(dy[:main].view(-1, chunk, dy.shape[1]).transpose(1, 2),
+                       x[:main].view(-1, chunk, x.shape[1])).float().sum(0)
+    if main < n:
+        tail = (dy[main:].t() @ x[main:]).float()
+        dw = tail if dw is None else dw + tail
+    return dw
+
+
+class FusedDecoderFn(torch.autograd.Function):
+    """attrs[N,16] = fused 5-head decoder(feats[N,32], pos[N,3]; 40 weight/bias tensors), differentiable w.r.t. feats
+    and the parameters.  Forward and activation-backward are the bf16-MFMA kernels; the weight gradients are split-K
+    GEMMs over the kept pre-activations (bf16)."""
+
+    @staticmethod
+    def forward(ctx, feats, pos, packed, packed_t, *params):
+        dev = feats.device
+        feats = feats.contiguous().float()
+        pos = pos.contiguous().float()
+        n = pos.shape[0]
+        cx = _capi.context_for(dev)
+        attrs = torch.empty((n, 16), dtype=torch.float32, device=dev)
+        zbuf = torch.empty((5, 3, n, HID), dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            cx.check(cx.lib.ggd_decoder_forward_train(
+                cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), C.c_void_p(feats.data_ptr()),
+                C.c_void_p(pos.data_ptr()), n, C.c_void_p(packed.data_ptr()), C.c_void_p(attrs.data_ptr()),
+                C.c_void_p(zbuf.data_ptr())))
+        ctx.save_for_backward(feats, pos, attrs, zbuf, packed_t)
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        return attrs
+
+    @staticmethod
+    def backward(ctx, dattrs):
+        feats, pos, attrs, zbuf, packed_t = ctx.saved_tensors
+        dev = feats.device
+        n = pos.shape[0]
+        dattrs = dattrs.contiguous().float()
+        cx = _capi.context_for(dev)
+        dzbuf = torch.empty((5, 3, n, HID), dtype=torch.bfloat16, device=dev)
+        dout = torch.empty((5, n, 4), dtype=torch.float32, device=dev)
+        dfeat = torch.empty((n, 32), dtype=torch.float32, device=dev)
+        dinfo = torch.empty((n, 16), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            cx.check(cx.lib.ggd_decoder_backward(
+                cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), n, C.c_void_p(packed_t.data_ptr()),
+                C.c_void_p(attrs.data_ptr()), C.c_void_p(dattrs.data_ptr()), C.c_void_p(zbuf.data_ptr()),
+                C.c_void_p(dzbuf.data_ptr()), C.c_void_p(dout.data_ptr()), C.c_void_p(dfeat.data_ptr()),
+                C.c_void_p(dinfo.data_ptr())))
+        bf = torch.bfloat16
+        info = torch.cat([pos, attrs[:, :11]], dim=1).to(bf)          # [N,14]: position + earlier heads' outputs
+        feats_b = feats.to(bf)
+        grads = []
+        for h in range(5):
+            x0 = torch.cat([feats_b, info[:, :3 + _N_EXTRA[h]]], dim=1)
+            acts = [x0] + [torch.nn.functional.gelu(zbuf[h, l].float()).to(bf) for l in range(3)]
+            for l in range(3):
+                dz = dzbuf[h, l]
+                grads += [_splitk_dw(dz, acts[l]), dz.float().sum(0)]
+            d4 = dout[h, :, :_OUT_DIM[h]]
+            grads += [_splitk_dw(d4.to(bf), acts[3]), d4.sum(0)]
+        return (dfeat, None, None, None, *grads)
+
+
+class FusedTrainDecoder(torch.nn.Module):
+    """Training front-end with the `SequentialDecoderReverse` call signature: tri-plane gather (HIP) + the fused
+    bf16-MFMA decoder with autograd.  Wraps (and shares the parameters of) a SequentialDecoderReverse."""
+
+    def __init__(self, decoder: SequentialDecoderReverse):
+        super().__init__()
+        self.decoder = decoder
+
+    def get_params_custom(self):
+        return self.decoder.get_params_custom()
+
+    def forward(self, feature_planes, init_position):
+        feats = triplane_mean(feature_planes, init_position, self.decoder.box_warp)
+        params = [t for head in _head_tensors(self.decoder) for t in head]
+        a = FusedDecoderFn.apply(feats, init_position, pack_weights(self.decoder), pack_weights_t(self.decoder), *params)
+        return SimpleNamespace(color=a[:, 0:3], opacity=a[:, 3:4], rotation=a[:, 4:8], scale=a[:, 8:11], xyz=a[:, 11:14])
+
+
 class FusedDecoder:
     def __init__(self, decoder: SequentialDecoderReverse):
         self.decoder = decoder

@@ -230,6 +230,26 @@ size_t ggd_decoder_packed_bytes(void);
 int ggd_decoder_forward(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
                         const void* packed_weights, float* attrs);
 
+/*
+ * Fused decoder, TRAINING.  ggd_decoder_forward_train == ggd_decoder_forward that also keeps the hidden layers'
+ * pre-activations: zbuf[5 heads][3 layers][N][128] bf16 (ggd_decoder_zbuf_bytes(N)).
+ * ggd_decoder_backward: given dattrs[N,16] (gradient w.r.t. the attrs rows) it back-propagates through the 5 heads
+ * (last first) with the TRANSPOSED weight image packed_t (ggd_decoder_packed_t_bytes(); built by
+ * fused_decoder.pack_weights_t) and writes
+ *   dzbuf [5][3][N][128] bf16  gradient at every hidden pre-activation
+ *   dout  [5][N][4]      fp32  gradient at every head's raw output (columns >= the head's width are zero)
+ *   dfeat [N,32]         fp32  gradient w.r.t. the plane features (sum over the 5 heads)
+ *   dinfo [N,16]         fp32  scratch (gradient carried between heads through the chained inputs)
+ * The weight / bias gradients are reductions over the N points of dz_l^T h_{l-1}; the caller forms them as split-K
+ * GEMMs from dzbuf / dout and the activations (fused_decoder.FusedDecoderFn).
+ */
+size_t ggd_decoder_zbuf_bytes(int32_t N);
+size_t ggd_decoder_packed_t_bytes(void);
+int ggd_decoder_forward_train(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
+                              const void* packed_weights, float* attrs, void* zbuf);
+int ggd_decoder_backward(ggd_ctx* ctx, void* stream, int32_t N, const void* packed_t, const float* attrs,
+                         const float* dattrs, const void* zbuf, void* dzbuf, float* dout, float* dfeat, float* dinfo);
+
 /* Per-stage device time (ms, hipEvent pairs on `stream`) of the most recent forward_geometry / forward_render /
  * backward call when profiling is on.  Stage names: ggd_stage_name(i), i in [0, ggd_stage_count()). */
 int ggd_set_profiling(ggd_ctx* ctx, int enabled);
