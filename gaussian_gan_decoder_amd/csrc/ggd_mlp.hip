@@ -245,6 +245,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void decoder_forward_kernel(const f
 }
 
 #include "ggd_mlp_bwd.inc"
+#include "ggd_mlp_wgrad.inc"
 
 }  // namespace
 
@@ -314,4 +315,31 @@ extern "C" int ggd_decoder_forward_train(ggd_ctx* ctx, void* stream, const float
                                          const void* packed_weights, float* attrs, void* zbuf) {
   if (ctx && N > 0 && !zbuf) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_forward_train: zbuf is NULL");
   return decoder_forward_impl(ctx, stream, feat, pos, N, packed_weights, attrs, zbuf);
+}
+
+extern "C" size_t ggd_decoder_wgrad_floats(void) { return (size_t)NHEAD * WG_HEAD_FLOATS; }
+
+extern "C" int ggd_decoder_wgrad(ggd_ctx* ctx, void* stream, int32_t N, const void* zbuf, const void* dzbuf,
+                                 const float* dout, const float* feat, const float* pos, const float* attrs,
+                                 float* wgrad) {
+  if (!ctx) return GGD_E_INVALID;
+  if (N < 0) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_wgrad: N < 0");
+  if (N == 0) return GGD_OK;
+  if (!zbuf || !dzbuf || !dout || !feat || !pos || !attrs || !wgrad)
+    return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_wgrad: NULL pointer");
+  static bool attr_set = false;
+  if (!attr_set) {
+    GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_wgrad_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
+    attr_set = true;
+  }
+  // split-K: ~4 workgroups per CU over the 20 (head, layer) problems; at least 4 stages per workgroup
+  int chunks = (N + 4 * WG_K - 1) / (4 * WG_K);
+  if (chunks > 64) chunks = 64;
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(chunks, NHEAD * 4), dim3(WG_THREADS), WG_LDS,
+                     static_cast<hipStream_t>(stream), N, static_cast<const __bf16*>(zbuf),
+                     static_cast<const __bf16*>(dzbuf), dout, feat, pos, attrs, wgrad);
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
 }

@@ -147,18 +147,23 @@ class FusedDecoderFn(torch.autograd.Function):
                 C.c_void_p(attrs.data_ptr()), C.c_void_p(dattrs.data_ptr()), C.c_void_p(zbuf.data_ptr()),
                 C.c_void_p(dzbuf.data_ptr()), C.c_void_p(dout.data_ptr()), C.c_void_p(dfeat.data_ptr()),
                 C.c_void_p(dinfo.data_ptr())))
-        bf = torch.bfloat16
-        info = torch.cat([pos, attrs[:, :11]], dim=1).to(bf)          # [N,14]: position + earlier heads' outputs
-        feats_b = feats.to(bf)
+        per_head = cx.lib.ggd_decoder_wgrad_floats() // 5
+        wg = torch.zeros((5, per_head), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            cx.check(cx.lib.ggd_decoder_wgrad(
+                cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), n, C.c_void_p(zbuf.data_ptr()),
+                C.c_void_p(dzbuf.data_ptr()), C.c_void_p(dout.data_ptr()), C.c_void_p(feats.data_ptr()),
+                C.c_void_p(pos.data_ptr()), C.c_void_p(attrs.data_ptr()), C.c_void_p(wg.data_ptr())))
         grads = []
         for h in range(5):
-            x0 = torch.cat([feats_b, info[:, :3 + _N_EXTRA[h]]], dim=1)
-            acts = [x0] + [torch.nn.functional.gelu(zbuf[h, l].float()).to(bf) for l in range(3)]
-            for l in range(3):
-                dz = dzbuf[h, l]
-                grads += [_splitk_dw(dz, acts[l]), dz.float().sum(0)]
-            d4 = dout[h, :, :_OUT_DIM[h]]
-            grads += [_splitk_dw(d4.to(bf), acts[3]), d4.sum(0)]
+            in_dim, od = 35 + _N_EXTRA[h], _OUT_DIM[h]
+            o = 0
+            for rows, cols, r_used, c_used in ((HID, 64, HID, in_dim), (HID, HID, HID, HID), (HID, HID, HID, HID),
+                                               (16, HID, od, HID)):
+                w = wg[h, o:o + rows * cols].view(rows, cols)[:r_used, :c_used]
+                o += rows * cols
+                grads += [w, wg[h, o:o + rows][:r_used]]
+                o += rows
         return (dfeat, None, None, None, *grads)
 
 
@@ -169,14 +174,25 @@ class FusedTrainDecoder(torch.nn.Module):
     def __init__(self, decoder: SequentialDecoderReverse):
         super().__init__()
         self.decoder = decoder
+        self._packed_key = None
+        self._packed = None
 
     def get_params_custom(self):
         return self.decoder.get_params_custom()
 
+    def _images(self, params):
+        """Weight images, rebuilt only when a parameter changed (optimizer steps bump Tensor._version)."""
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key != self._packed_key:
+            self._packed = (pack_weights(self.decoder), pack_weights_t(self.decoder))
+            self._packed_key = key
+        return self._packed
+
     def forward(self, feature_planes, init_position):
         feats = triplane_mean(feature_planes, init_position, self.decoder.box_warp)
         params = [t for head in _head_tensors(self.decoder) for t in head]
-        a = FusedDecoderFn.apply(feats, init_position, pack_weights(self.decoder), pack_weights_t(self.decoder), *params)
+        packed, packed_t = self._images(params)
+        a = FusedDecoderFn.apply(feats, init_position, packed, packed_t, *params)
         return SimpleNamespace(color=a[:, 0:3], opacity=a[:, 3:4], rotation=a[:, 4:8], scale=a[:, 8:11], xyz=a[:, 11:14])
 
 

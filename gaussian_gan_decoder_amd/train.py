@@ -62,7 +62,8 @@ class DecoderTrainer:
 
     def __init__(self, device, n_scenes_total: int, plane_res: int = 256, plane_channels: int = 32,
                  hidden_dim: int = 128, lr: float = 9e-5, image_size: int = 512, render_fn=None, seed: int = 0,
-                 l1_weight: float = 0.2, l2_weight: float = 1.0, process_group=None, fused_activations: bool = False):
+                 l1_weight: float = 0.2, l2_weight: float = 1.0, process_group=None, fused_activations: bool = False,
+                 fused_decoder: bool = False):
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.pg = process_group
@@ -77,6 +78,11 @@ class DecoderTrainer:
         self.planes = torch.nn.Parameter(
             (0.5 * torch.randn(3, plane_channels, plane_res, plane_res, generator=g)).to(self.device))
         self.latents = (1.0 + 0.25 * torch.randn(n_scenes_total, plane_channels, generator=g)).to(self.device)
+        # fused_decoder: bf16-MFMA decoder kernels (forward + activation backward) instead of the PyTorch module
+        self.decoder_fwd = self.decoder
+        if fused_decoder:
+            from .fused_decoder import FusedTrainDecoder
+            self.decoder_fwd = FusedTrainDecoder(self.decoder)
         self.params = self.decoder.get_params_custom() + [self.planes]
         self.broadcast_parameters()
         self.optim = torch.optim.Adam([{"params": self.params, "lr": lr}])
@@ -124,7 +130,7 @@ class DecoderTrainer:
         B = batch.positions.shape[0]
         for b in range(B):
             planes = self.planes * self.latents[int(batch.scene_id[b])][None, :, None, None]
-            out = self.decoder(planes, batch.positions[b])
+            out = self.decoder_fwd(planes, batch.positions[b])
             gs = self.gaussians
             gs._xyz, gs._scaling, gs._rotation = out.xyz, out.scale, out.rotation
             gs._opacity, gs._features_dc = out.opacity, out.color.unsqueeze(1)

@@ -250,6 +250,19 @@ int ggd_decoder_forward_train(ggd_ctx* ctx, void* stream, const float* feat, con
 int ggd_decoder_backward(ggd_ctx* ctx, void* stream, int32_t N, const void* packed_t, const float* attrs,
                          const float* dattrs, const void* zbuf, void* dzbuf, float* dout, float* dfeat, float* dinfo);
 
+/*
+ * Weight / bias gradients of the fused decoder: split-K MFMA GEMMs over the points, operands transposed through LDS
+ * (ds_read_b64_tr_b16), gelu(z) recomputed on the fly.  ACCUMULATES (fp32 atomics) into wgrad, which the caller
+ * zero-initialises: ggd_decoder_wgrad_floats() floats = 5 heads x
+ *   { dW1[128][64] db1[128] dW2[128][128] db2[128] dW3[128][128] db3[128] dW4[16][128] db4[16] }
+ * (dW1 columns: 32 plane features, 3 position, then the earlier heads' outputs; columns / rows past the layer's real
+ * width are padding).  feat / pos / attrs as in ggd_decoder_forward_train, zbuf from it, dzbuf / dout from
+ * ggd_decoder_backward.
+ */
+size_t ggd_decoder_wgrad_floats(void);
+int ggd_decoder_wgrad(ggd_ctx* ctx, void* stream, int32_t N, const void* zbuf, const void* dzbuf, const float* dout,
+                      const float* feat, const float* pos, const float* attrs, float* wgrad);
+
 /* Per-stage device time (ms, hipEvent pairs on `stream`) of the most recent forward_geometry / forward_render /
  * backward call when profiling is on.  Stage names: ggd_stage_name(i), i in [0, ggd_stage_count()). */
 int ggd_set_profiling(ggd_ctx* ctx, int enabled);

@@ -3,7 +3,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gaussian_gan_decoder_amd.train import DecoderTrainer, make_scene_batch
 dev = torch.device('cuda:0')
-tr = DecoderTrainer(dev, n_scenes_total=4, image_size=512)
+fused = '--fused' in sys.argv
+tr = DecoderTrainer(dev, n_scenes_total=4, image_size=512, fused_activations=True, fused_decoder=fused)
 b = make_scene_batch([0,1,2,3], 500000, 512, dev, seed=0)
 for _ in range(2): tr.step(b)
 torch.cuda.synchronize()
