@@ -240,33 +240,48 @@ def main():
     # ---- data-parallel decoder train step (BASELINE configs 3/5): scenes_per_gpu scenes per rank, 512x512,
     #      decoder MLPs -> activations -> raster fwd -> L1+L2 -> bwd -> ONE flat RCCL all-reduce -> Adam
     train = None
+    train_fused = None
     if not args.no_train:
         from gaussian_gan_decoder_amd.train import DecoderTrainer, make_scene_batch
         spg = args.scenes_per_gpu
-        tr = DecoderTrainer(dev, n_scenes_total=spg * world, image_size=512, fused_activations=True)
         my_scenes = list(range(rank * spg, (rank + 1) * spg))
         batches = [make_scene_batch(my_scenes, args.train_points, 512, dev, seed=i) for i in range(2)]
-        for i in range(2):
-            tr.step(batches[i % 2])
-        barrier()
-        tt = time.perf_counter()
-        for i in range(args.train_iters):
-            tr.step(batches[i % 2])
-        barrier()
-        t_train = time.perf_counter() - tt
-        if dist is not None:
-            t = torch.tensor([t_train], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            t_train = float(t.item())
-        nparam = sum(p.numel() for p in tr.params)
-        train = {"iters_per_s": args.train_iters / t_train, "scenes_per_s": args.train_iters * spg * world / t_train,
-                 "ms_per_iter": t_train / args.train_iters * 1e3, "global_batch": spg * world,
-                 "scenes_per_gpu": spg, "points_per_scene": args.train_points, "image": "512x512",
-                 "allreduce_bytes": nparam * 4 if world > 1 else 0,
-                 "mlp_dtype": "fp32",
-                 "step": "tri-plane gather (HIP) -> decoder MLPs (PyTorch fp32; bf16 autocast measured: no gain, the "
-                         "tall-skinny GEMMs are HBM-bound) -> HIP raster fwd (activations fused) -> L1+L2 -> bwd -> flat all-reduce -> Adam"}
-        del tr, batches
+
+        def run_train(fused_decoder):
+            tr = DecoderTrainer(dev, n_scenes_total=spg * world, image_size=512, fused_activations=True,
+                                fused_decoder=fused_decoder)
+            for i in range(2):
+                tr.step(batches[i % 2])
+            barrier()
+            tt = time.perf_counter()
+            for i in range(args.train_iters):
+                tr.step(batches[i % 2])
+            barrier()
+            t_train = time.perf_counter() - tt
+            if dist is not None:
+                t = torch.tensor([t_train], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                t_train = float(t.item())
+            nparam = sum(p.numel() for p in tr.params)
+            del tr
+            return {"iters_per_s": args.train_iters / t_train,
+                    "scenes_per_s": args.train_iters * spg * world / t_train,
+                    "ms_per_iter": t_train / args.train_iters * 1e3, "global_batch": spg * world,
+                    "scenes_per_gpu": spg, "points_per_scene": args.train_points, "image": "512x512",
+                    "allreduce_bytes": nparam * 4 if world > 1 else 0}
+
+        # (1) the reference's precision: decoder MLPs in fp32 (PyTorch GEMMs, split-K weight gradients)
+        train = run_train(False)
+        train["mlp_dtype"] = "fp32"
+        train["step"] = ("tri-plane gather (HIP) -> decoder MLPs (PyTorch fp32) -> HIP raster fwd (activations fused) -> "
+                         "L1+L2 -> bwd -> flat all-reduce -> Adam")
+        # (2) SURVEY 8f row 1: decoder forward / activation backward / weight gradients as bf16-MFMA HIP kernels
+        #     (fp32 accumulate, fp32 master weights and optimizer) -- reported beside (1), never instead of it
+        train_fused = run_train(True)
+        train_fused["mlp_dtype"] = "bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16)"
+        train_fused["step"] = ("tri-plane gather (HIP) -> fused 5-head decoder (HIP MFMA fwd, bwd, split-K wgrad; all "
+                               "local scenes in one launch) -> HIP raster fwd/bwd -> flat all-reduce -> Adam")
+        del batches
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -307,6 +322,8 @@ def main():
         result["decode_render"] = decode
     if train is not None:
         result["train"] = train
+    if train_fused is not None:
+        result["train_fused_decoder"] = train_fused
     if extra:
         result["extra"] = extra
     if not args.no_cpu_baseline:

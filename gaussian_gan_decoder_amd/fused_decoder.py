@@ -188,6 +188,16 @@ class FusedTrainDecoder(torch.nn.Module):
             self._packed_key = key
         return self._packed
 
+    def forward_scenes(self, planes_list, positions):
+        """Several scenes (own feature planes, positions[B,N,3]) through ONE decoder launch: attrs[B,N,16].  The
+        weight gradients are then formed once per step instead of once per scene."""
+        B, N = positions.shape[0], positions.shape[1]
+        feats = torch.cat([triplane_mean(planes_list[b], positions[b], self.decoder.box_warp) for b in range(B)], dim=0)
+        params = [t for head in _head_tensors(self.decoder) for t in head]
+        packed, packed_t = self._images(params)
+        a = FusedDecoderFn.apply(feats, positions.reshape(B * N, 3), packed, packed_t, *params)
+        return a.view(B, N, 16)
+
     def forward(self, feature_planes, init_position):
         feats = triplane_mean(feature_planes, init_position, self.decoder.box_warp)
         params = [t for head in _head_tensors(self.decoder) for t in head]

@@ -80,6 +80,7 @@ class DecoderTrainer:
         self.latents = (1.0 + 0.25 * torch.randn(n_scenes_total, plane_channels, generator=g)).to(self.device)
         # fused_decoder: bf16-MFMA decoder kernels (forward + activation backward) instead of the PyTorch module
         self.decoder_fwd = self.decoder
+        self.fused_decoder = bool(fused_decoder)
         if fused_decoder:
             from .fused_decoder import FusedTrainDecoder
             self.decoder_fwd = FusedTrainDecoder(self.decoder)
@@ -128,12 +129,22 @@ class DecoderTrainer:
         """Decoder + raster forward for the local scenes; returns the mean loss over them."""
         total = 0.0
         B = batch.positions.shape[0]
+        scene_ids = batch.scene_id.tolist()
+        attrs = None
+        if self.fused_decoder:   # all local scenes through one decoder launch
+            attrs = self.decoder_fwd.forward_scenes(
+                [self.planes * self.latents[s][None, :, None, None] for s in scene_ids], batch.positions)
         for b in range(B):
-            planes = self.planes * self.latents[int(batch.scene_id[b])][None, :, None, None]
-            out = self.decoder_fwd(planes, batch.positions[b])
             gs = self.gaussians
-            gs._xyz, gs._scaling, gs._rotation = out.xyz, out.scale, out.rotation
-            gs._opacity, gs._features_dc = out.opacity, out.color.unsqueeze(1)
+            if attrs is not None:
+                a = attrs[b]
+                gs._xyz, gs._scaling, gs._rotation = a[:, 11:14], a[:, 8:11], a[:, 4:8]
+                gs._opacity, gs._features_dc = a[:, 3:4], a[:, 0:3].unsqueeze(1)
+            else:
+                planes = self.planes * self.latents[scene_ids[b]][None, :, None, None]
+                out = self.decoder_fwd(planes, batch.positions[b])
+                gs._xyz, gs._scaling, gs._rotation = out.xyz, out.scale, out.rotation
+                gs._opacity, gs._features_dc = out.opacity, out.color.unsqueeze(1)
             fov = float(batch.fov_deg[b]) / 360 * 2 * math.pi
             cam = CustomCam(size=self.image_size, fov=fov, extr=batch.cam2world[b])
             image = self.render_fn(cam, gs, bg_color=self.bg, **self.render_kwargs)["render"][:3]

@@ -12,6 +12,7 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     tr.step(b); torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=60))
+if "--cpu" in sys.argv: print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=30, max_name_column_width=60))
 t=time.perf_counter()
 for _ in range(3): tr.step(b)
 torch.cuda.synchronize(); print('ms/iter', (time.perf_counter()-t)/3*1e3)
