@@ -87,6 +87,25 @@ def cpu_baseline(P, S, kind, budget_s=25.0):
             "host_cores": os.cpu_count()}
 
 
+def pmc_traffic(workload, stage):
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    corrected as profiles/*/traffic.json states).  bench.py cannot collect counters itself; the number is the one
+    measured with `rocprofv3 --pmc` on this same command (profiles/r01_final/).  None when no profile of this workload."""
+    import glob
+    best = None
+    for fn in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "traffic.json"))):
+        try:
+            doc = json.load(open(fn))
+        except (OSError, ValueError):
+            continue
+        if doc.get("workload") != workload:
+            continue
+        k = doc.get("kernels", {}).get(doc.get("stage_to_kernel", {}).get(stage, ""))
+        if k:
+            best = k["hbm_bytes"]
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -312,7 +331,7 @@ def main():
                                "raster fp32, inputs resident in HBM", "num_rendered": num_rendered,
                    "tiles": ((S + 15) // 16) ** 2, "parallelism": f"scene-parallel x{world} (no collective)"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, dom),
                      "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": stage_ms[dom]},
         "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
         "whole_frame": {"algorithmic_bytes": whole, "GBps": whole / (ms_per_step * 1e-3) / 1e9,
