@@ -243,8 +243,7 @@ template <int EXP_MODE, bool CULL>
 __global__ __launch_bounds__(64) void blend_backward_kernel(
     int W, int H, int gx, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ list,
     const uint32_t* __restrict__ ranges, const float* __restrict__ bg, const float* __restrict__ final_T,
-    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D,
-    float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors) {
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
   __shared__ float4 s_rec[64 * 3];
   __shared__ float s_sum[64 * 9];  // [record slot][component], written by lane 63 only
   const int lane = threadIdx.x;
@@ -393,15 +392,17 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
     if (lane < n && ((touched >> lane) & 1ull)) {
       const float* o = s_sum + lane * 9;
       const size_t id = my_id;
-      atomicAdd(dL_dcolors + 3 * id + 0, o[0]);
-      atomicAdd(dL_dcolors + 3 * id + 1, o[1]);
-      atomicAdd(dL_dcolors + 3 * id + 2, o[2]);
-      atomicAdd(dL_dopacity + id, o[3]);
-      atomicAdd(dL_dconic + 4 * id + 0, o[4]);
-      atomicAdd(dL_dconic + 4 * id + 1, o[5]);
-      atomicAdd(dL_dconic + 4 * id + 2, o[6]);
-      atomicAdd(dL_dmean2D + 3 * id + 0, o[7]);
-      atomicAdd(dL_dmean2D + 3 * id + 1, o[8]);
+      // one 48-byte accumulator record per Gaussian (GGD_ACC_*): the 9 atomics of a record land in one cache line
+      float* a = grad_acc + GGD_ACC_FLOATS * id;
+      atomicAdd(a + GGD_ACC_COLOR + 0, o[0]);
+      atomicAdd(a + GGD_ACC_COLOR + 1, o[1]);
+      atomicAdd(a + GGD_ACC_COLOR + 2, o[2]);
+      atomicAdd(a + GGD_ACC_OPACITY, o[3]);
+      atomicAdd(a + GGD_ACC_CONIC + 0, o[4]);
+      atomicAdd(a + GGD_ACC_CONIC + 1, o[5]);
+      atomicAdd(a + GGD_ACC_CONIC + 2, o[6]);
+      atomicAdd(a + GGD_ACC_MEAN2D + 0, o[7]);
+      atomicAdd(a + GGD_ACC_MEAN2D + 1, o[8]);
     }
     cend = cstart;
   }
@@ -440,16 +441,14 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
 
 int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
                               const uint32_t* list, const uint32_t* ranges, const float* final_T,
-                              const uint32_t* n_contrib, const float* dL_dpix, float* dL_dmean2D,
-                              float* dL_dconic, float* dL_dopacity, float* dL_dcolors) {
+                              const uint32_t* n_contrib, const float* dL_dpix, float* grad_acc) {
   const int gx = (prm.width + 15) / 16, gy = (prm.height + 15) / 16;
   if (gx * gy == 0) return GGD_OK;
   const int em = ctx->opt[GGD_OPT_EXP_MODE];
   const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
 #define GGD_LAUNCH_BWD(EM, CU)                                                                                    \
   hipLaunchKernelGGL((blend_backward_kernel<EM, CU>), dim3(gx * gy), dim3(64), 0, s, prm.width, prm.height, gx,  \
-                     splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, \
-                     dL_dcolors)
+                     splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc)
   if (cull) {
     if (em == 0) GGD_LAUNCH_BWD(0, true); else if (em == 1) GGD_LAUNCH_BWD(1, true); else GGD_LAUNCH_BWD(2, true);
   } else {

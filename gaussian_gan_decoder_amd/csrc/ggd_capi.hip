@@ -457,30 +457,28 @@ extern "C" int ggd_backward(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
   const float* final_T = reinterpret_cast<const float*>(ib + iv.final_T);
   const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(ib + iv.n_contrib);
 
-  rc = ggd_reserve_scratch(ctx, ggd_align((size_t)P * 4 * sizeof(float)), s);
+  const size_t acc_bytes = (size_t)P * GGD_ACC_FLOATS * sizeof(float);
+  rc = ggd_reserve_scratch(ctx, ggd_align(acc_bytes), s);
   if (rc != GGD_OK) return rc;
-  float* dL_dconic = static_cast<float*>(ctx->scratch);
-
-  GGD_HIP(hipMemsetAsync(dL_dconic, 0, (size_t)P * 4 * sizeof(float), s));
-  GGD_HIP(hipMemsetAsync(dL_dmeans2D, 0, (size_t)P * 3 * sizeof(float), s));
-  GGD_HIP(hipMemsetAsync(dL_dcolors, 0, (size_t)P * 3 * sizeof(float), s));
-  GGD_HIP(hipMemsetAsync(dL_dopacity, 0, (size_t)P * sizeof(float), s));
-  GGD_HIP(hipMemsetAsync(dL_dmeans3D, 0, (size_t)P * 3 * sizeof(float), s));
-  GGD_HIP(hipMemsetAsync(dL_dcov3D, 0, (size_t)P * 6 * sizeof(float), s));
-  GGD_HIP(hipMemsetAsync(dL_dscales, 0, (size_t)P * 3 * sizeof(float), s));
-  GGD_HIP(hipMemsetAsync(dL_drots, 0, (size_t)P * 4 * sizeof(float), s));
-  if (prm->M > 0 && dL_dsh) GGD_HIP(hipMemsetAsync(dL_dsh, 0, (size_t)P * prm->M * 3 * sizeof(float), s));
+  float* grad_acc = static_cast<float*>(ctx->scratch);
+  // the only zero-fill of the backward: the accumulator records.  Every caller array is written in full by the
+  // per-Gaussian kernel, except the ones a mode never produces (kept zero like upstream's zero-initialised outputs).
+  GGD_HIP(hipMemsetAsync(grad_acc, 0, acc_bytes, s));
+  if (cov3D_precomp) {
+    GGD_HIP(hipMemsetAsync(dL_dscales, 0, (size_t)P * 3 * sizeof(float), s));
+    GGD_HIP(hipMemsetAsync(dL_drots, 0, (size_t)P * 4 * sizeof(float), s));
+  }
+  if (colors_precomp && prm->M > 0 && dL_dsh) GGD_HIP(hipMemsetAsync(dL_dsh, 0, (size_t)P * prm->M * 3 * sizeof(float), s));
 
   if (R > 0) {
     StageTimer t(ctx, ST_BLEND_BWD, s);
-    rc = ggd_launch_blend_backward(ctx, s, *prm, splat, list, ranges, final_T, n_contrib, dL_dpix, dL_dmeans2D,
-                                   dL_dconic, dL_dopacity, dL_dcolors);
+    rc = ggd_launch_blend_backward(ctx, s, *prm, splat, list, ranges, final_T, n_contrib, dL_dpix, grad_acc);
     if (rc != GGD_OK) return rc;
   }
   {
     StageTimer t(ctx, ST_PREPROCESS_BWD, s);
     rc = ggd_launch_preprocess_backward(ctx, s, *prm, means3D, shs, colors_precomp, opacities, dL_dopacity, scales, rotations,
-                                        cov3D_precomp, radii, shs ? clamped : nullptr, dL_dmeans2D, dL_dconic,
+                                        cov3D_precomp, radii, shs ? clamped : nullptr, grad_acc, dL_dmeans2D,
                                         dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots);
     if (rc != GGD_OK) return rc;
   }

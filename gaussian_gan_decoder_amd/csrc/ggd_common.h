@@ -94,16 +94,20 @@ int ggd_launch_ranges(ggd_ctx* ctx, hipStream_t s, const uint64_t* keys, int64_t
 int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
                      const uint32_t* list, const uint32_t* ranges, uint32_t capacity, float* out_color, float* final_T,
                      uint32_t* n_contrib);
+// Backward accumulator record (library scratch, one per Gaussian, zeroed with ONE memset): the blend backward adds its
+// per-(tile, Gaussian) sums here, the per-Gaussian backward reads it once and writes every caller-visible gradient
+// (zeros for culled Gaussians), so the caller's 8 gradient arrays need no zero-fill passes.
+constexpr int GGD_ACC_FLOATS = 12;   // 48 B: conic A,B,C | opacity | mean2D x,y | colour r,g,b | 3 pad
+constexpr int GGD_ACC_CONIC = 0, GGD_ACC_OPACITY = 3, GGD_ACC_MEAN2D = 4, GGD_ACC_COLOR = 6;
 int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
                               const uint32_t* list, const uint32_t* ranges, const float* final_T,
-                              const uint32_t* n_contrib, const float* dL_dpix, float* dL_dmean2D /*[P,3]*/,
-                              float* dL_dconic /*[P,4]*/, float* dL_dopacity, float* dL_dcolors);
+                              const uint32_t* n_contrib, const float* dL_dpix, float* grad_acc /*[P][GGD_ACC_FLOATS]*/);
 int ggd_launch_preprocess_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const float* means3D,
                                    const float* shs, const float* colors_precomp, const float* opacities,
                                    float* dL_dopacity, const float* scales,
                                    const float* rotations, const float* cov3D_precomp, const int32_t* radii,
-                                   const uint8_t* clamped, const float* dL_dmean2D, const float* dL_dconic,
-                                   const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                                   const uint8_t* clamped, const float* grad_acc, float* dL_dmean2D,
+                                   float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                                    float* dL_dscales, float* dL_drots);
 
 // ---- device helpers -----------------------------------------------------------------------------------------

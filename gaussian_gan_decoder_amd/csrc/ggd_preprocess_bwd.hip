@@ -21,13 +21,33 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
     const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,
-    const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic, const float* __restrict__ dL_dcolors,
+    const float* __restrict__ grad_acc, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drots) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
-  if (radii[i] <= 0) return;  // outputs were zero-filled by the caller
   const size_t ii = (size_t)i;
+  if (radii[i] <= 0) {  // culled: every gradient of this Gaussian is zero (the caller does not pre-fill the arrays)
+    dL_dmean2D[3 * ii] = 0.0f; dL_dmean2D[3 * ii + 1] = 0.0f; dL_dmean2D[3 * ii + 2] = 0.0f;
+    dL_dcolors[3 * ii] = 0.0f; dL_dcolors[3 * ii + 1] = 0.0f; dL_dcolors[3 * ii + 2] = 0.0f;
+    dL_dopacity[i] = 0.0f;
+    dL_dmeans3D[3 * ii] = 0.0f; dL_dmeans3D[3 * ii + 1] = 0.0f; dL_dmeans3D[3 * ii + 2] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * ii + k] = 0.0f;
+    if (!colors_precomp)
+      for (int k = 0; k < 3 * M; ++k) dL_dsh[ii * M * 3 + k] = 0.0f;
+    if (!cov3D_precomp) {
+      dL_dscales[3 * ii] = 0.0f; dL_dscales[3 * ii + 1] = 0.0f; dL_dscales[3 * ii + 2] = 0.0f;
+      reinterpret_cast<float4*>(dL_drots)[i] = make_float4(0, 0, 0, 0);
+    }
+    return;
+  }
+  const float4 acc0 = reinterpret_cast<const float4*>(grad_acc)[3 * ii];      // conic A, B, C | opacity
+  const float4 acc1 = reinterpret_cast<const float4*>(grad_acc)[3 * ii + 1];  // mean2D x, y | colour r, g
+  const float4 acc2 = reinterpret_cast<const float4*>(grad_acc)[3 * ii + 2];  // colour b
+  const float gcol3[3] = {acc1.z, acc1.w, acc2.x};
+  dL_dmean2D[3 * ii] = acc1.x; dL_dmean2D[3 * ii + 1] = acc1.y; dL_dmean2D[3 * ii + 2] = 0.0f;
+  dL_dcolors[3 * ii] = gcol3[0]; dL_dcolors[3 * ii + 1] = gcol3[1]; dL_dcolors[3 * ii + 2] = gcol3[2];
   const Mat16 V = load_mat(view);
   const Mat16 PV = load_mat(proj);
   const float p[3] = {means3D[3 * ii], means3D[3 * ii + 1], means3D[3 * ii + 2]};
@@ -66,8 +86,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     const float a = abc[0] + 0.3f, b = abc[1], c = abc[2] + 0.3f;
     const float denom = a * c - b * b;
     const float denom2inv = 1.0f / (denom * denom + 0.0000001f);
-    const float4 gcon = reinterpret_cast<const float4*>(dL_dconic)[i];
-    const float gA = gcon.x, gB = gcon.y, gC = gcon.z;
+    const float gA = acc0.x, gB = acc0.y, gC = acc0.z;
     float dL_da = 0.0f, dL_db = 0.0f, dL_dc = 0.0f;
     if (denom2inv != 0.0f) {
       dL_da = denom2inv * (-c * c * gA + 2.0f * b * c * gB + (denom - a * c) * gC);
@@ -113,7 +132,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     const float h3 = PV.m[3] * p[0] + PV.m[7] * p[1] + PV.m[11] * p[2] + PV.m[15];
     const float m_w = 1.0f / (h3 + 0.0000001f);
     const float mul1 = h0 * m_w * m_w, mul2 = h1 * m_w * m_w;
-    const float g0 = dL_dmean2D[3 * ii], g1 = dL_dmean2D[3 * ii + 1];
+    const float g0 = acc1.x, g1 = acc1.y;
     dmean[0] += (PV.m[0] * m_w - PV.m[3] * mul1) * g0 + (PV.m[1] * m_w - PV.m[3] * mul2) * g1;
     dmean[1] += (PV.m[4] * m_w - PV.m[7] * mul1) * g0 + (PV.m[5] * m_w - PV.m[7] * mul2) * g1;
     dmean[2] += (PV.m[8] * m_w - PV.m[11] * mul1) * g0 + (PV.m[9] * m_w - PV.m[11] * mul2) * g1;
@@ -129,7 +148,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     float ddir[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float gcol = ((cl >> c) & 1u) ? 0.0f : dL_dcolors[3 * ii + c];
+      const float gcol = ((cl >> c) & 1u) ? 0.0f : gcol3[c];
 #define SHK(k) sh[(k) * 3 + c]
 #define DSH(k) dsh[(k) * 3 + c]
       float dx = 0.0f, dy = 0.0f, dz = 0.0f;
@@ -235,9 +254,11 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     }
     reinterpret_cast<float4*>(dL_drots)[i] = dq;
   }
-  if (raw) {  // sigmoid'(x) = s (1 - s), applied in place to the blend's dL/d(opacity)
+  if (raw) {  // sigmoid'(x) = s (1 - s) applied to the blend's dL/d(opacity)
     const float sg = act_sigmoid(opacities_raw[i]);
-    dL_dopacity[i] = dL_dopacity[i] * (sg * (1.0f - sg));
+    dL_dopacity[i] = acc0.w * (sg * (1.0f - sg));
+  } else {
+    dL_dopacity[i] = acc0.w;
   }
 }
 
@@ -247,14 +268,14 @@ int ggd_launch_preprocess_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params
                                    const float* shs, const float* colors_precomp, const float* opacities,
                                    float* dL_dopacity, const float* scales,
                                    const float* rotations, const float* cov3D_precomp, const int32_t* radii,
-                                   const uint8_t* clamped, const float* dL_dmean2D, const float* dL_dconic,
-                                   const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                                   const uint8_t* clamped, const float* grad_acc, float* dL_dmean2D,
+                                   float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                                    float* dL_dscales, float* dL_drots) {
   if (prm.P == 0) return GGD_OK;
   hipLaunchKernelGGL(preprocess_backward_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, s, prm.P, prm.M,
                      prm.sh_degree, prm.width, prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier,
                      prm.raw_attributes, opacities, dL_dopacity, prm.viewmatrix, prm.projmatrix, prm.campos, means3D, shs, colors_precomp, scales, rotations,
-                     cov3D_precomp, radii, clamped, dL_dmean2D, dL_dconic, dL_dcolors, dL_dmeans3D, dL_dcov3D,
+                     cov3D_precomp, radii, clamped, grad_acc, dL_dmean2D, dL_dcolors, dL_dmeans3D, dL_dcov3D,
                      dL_dsh, dL_dscales, dL_drots);
   GGD_HIP(hipGetLastError());
   return GGD_OK;

@@ -99,6 +99,7 @@ def decode_buffers(P, W, H, R, geom, binning, img, layout_R=None):
 
 def run_native_backward(d, n, dL_dpix, device="cuda:0"):
     from gaussian_gan_decoder_amd import rasterizer as R
+    R.POISON_OUTPUTS = True   # NaN-fill the gradient arrays first: every element must be written by the library
     dev = torch.device(device)
     t = lambda x: torch.empty(0, device=dev) if x is None else x.to(dev)
     outs = R.rasterize_gaussians_backward_native(
