@@ -124,6 +124,9 @@ class Context:
     def set_option(self, option: int, value: int):
         self.check(self.lib.ggd_set_option(self.handle, int(option), int(value)))
 
+    def get_option(self, option: int) -> int:
+        return int(self.lib.ggd_get_option(self.handle, int(option)))
+
     def blend_stats(self, enable: bool):
         """Start/stop the forward-blend work counters; returns the counters gathered since the last start."""
         out = (C.c_ulonglong * 5)()

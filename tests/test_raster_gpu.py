@@ -118,3 +118,33 @@ def test_single_call_forward_capacity_overflow_is_retried(native_lib):
     n_big2 = run_native(big, debug=False, binning=2)                # now the hint fits: speculative path succeeds
     np.testing.assert_array_equal(n_big2["point_list"], o_big["point_list"])
     np.testing.assert_array_equal(n_big2["color"].cpu().numpy(), n_big["color"].cpu().numpy())
+
+
+def test_blend_options_do_not_change_the_image(native_lib):
+    """Wave-level culling (GGD_OPT_BLEND_CULL) and the two-waves-per-tile split (GGD_OPT_BLEND_SPLIT) are exact
+    optimisations: image, final_T and n_contrib are bit-identical with them on or off.  The exp variants
+    (GGD_OPT_EXP_MODE 0/1/2) may differ by ulps only: <= 1e-5 against each other."""
+    from gaussian_gan_decoder_amd import _capi
+    d = scene_inputs(P=20000, size=256, kind="shell", lsm=-4.5)
+    cx = _capi.context_for(torch.device("cuda:0"))
+    saved = [cx.get_option(o) for o in (_capi.OPT_EXP_MODE, _capi.OPT_BLEND_CULL, _capi.OPT_BLEND_SPLIT)]
+    try:
+        base = run_native(d, debug=False)
+        for cull in (0, 1):
+            for split in (0, 1):
+                cx.set_option(_capi.OPT_BLEND_CULL, cull); cx.set_option(_capi.OPT_BLEND_SPLIT, split)
+                n = run_native(d, debug=False)
+                np.testing.assert_array_equal(n["color"].cpu().numpy(), base["color"].cpu().numpy())
+                np.testing.assert_array_equal(n["n_contrib"], base["n_contrib"])
+                np.testing.assert_array_equal(n["final_T"], base["final_T"])
+        cx.set_option(_capi.OPT_BLEND_CULL, saved[1]); cx.set_option(_capi.OPT_BLEND_SPLIT, saved[2])
+        for em in (0, 1, 2):
+            cx.set_option(_capi.OPT_EXP_MODE, em)
+            n = run_native(d, debug=False)
+            same = n["n_contrib"] == base["n_contrib"]
+            assert (~same).sum() <= 2
+            err = np.abs(n["color"].cpu().numpy() - base["color"].cpu().numpy())[:, same]
+            assert err.max() <= RGB_ATOL
+    finally:
+        for o, v in zip((_capi.OPT_EXP_MODE, _capi.OPT_BLEND_CULL, _capi.OPT_BLEND_SPLIT), saved):
+            cx.set_option(o, v)

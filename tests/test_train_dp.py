@@ -88,3 +88,18 @@ def test_decoder_matches_reference_fixture():
     dec.load_state_dict({k[len("sd_"):]: torch.from_numpy(f[k]) for k in f.files if k.startswith("sd_")})
     out = dec(pf, pos)
     np.testing.assert_allclose(out.detach().numpy(), f["decoder_out"], atol=1e-5, rtol=1e-5)
+
+
+def test_sequential_decoder_matches_reference_class_fixture():
+    """tests/golden/sequential_decoder_fixture.npz: outputs of the REFERENCE's SequentialDecoderReverse
+    (main/decoder_models/sequential_decoder_reverse.py, run by tests/golden/make_decoder_golden.py) for seeded planes,
+    positions and weights.  Our module must load its state_dict unchanged and reproduce all five heads."""
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sequential_decoder_fixture.npz"))
+    dec = SequentialDecoderReverse()
+    sd = {k[len("sd_"):]: torch.from_numpy(f[k]) for k in f.files if k.startswith("sd_")}
+    missing, unexpected = dec.load_state_dict(sd, strict=False)
+    assert not unexpected and not [m for m in missing if "decoder" in m], (missing, unexpected)
+    with torch.no_grad():
+        out = dec(torch.from_numpy(f["planes"]), torch.from_numpy(f["positions"]))
+    for k in ("color", "opacity", "rotation", "scale", "xyz"):
+        np.testing.assert_allclose(getattr(out, k).numpy(), f[k], atol=2e-5, rtol=1e-5, err_msg=k)
