@@ -268,7 +268,7 @@ def main():
 
         def run_train(fused_decoder):
             tr = DecoderTrainer(dev, n_scenes_total=spg * world, image_size=512, fused_activations=True,
-                                fused_decoder=fused_decoder)
+                                fused_decoder=fused_decoder, fused_loss=True)
             for i in range(2):
                 tr.step(batches[i % 2])
             barrier()
@@ -293,13 +293,14 @@ def main():
         train = run_train(False)
         train["mlp_dtype"] = "fp32"
         train["step"] = ("tri-plane gather (HIP) -> decoder MLPs (PyTorch fp32) -> HIP raster fwd (activations fused) -> "
-                         "L1+L2 -> bwd -> flat all-reduce -> Adam")
+                         "L1+L2+SSIM+Sobel (fused HIP loss, reference weights) -> bwd -> flat all-reduce -> Adam")
         # (2) SURVEY 8f row 1: decoder forward / activation backward / weight gradients as bf16-MFMA HIP kernels
         #     (fp32 accumulate, fp32 master weights and optimizer) -- reported beside (1), never instead of it
         train_fused = run_train(True)
         train_fused["mlp_dtype"] = "bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16)"
         train_fused["step"] = ("tri-plane gather (HIP) -> fused 5-head decoder (HIP MFMA fwd, bwd, split-K wgrad; all "
-                               "local scenes in one launch) -> HIP raster fwd/bwd -> flat all-reduce -> Adam")
+                               "local scenes in one launch) -> HIP raster fwd -> L1+L2+SSIM+Sobel (fused HIP loss) -> bwd -> "
+                               "flat all-reduce -> Adam")
         del batches
     if rank != 0:
         if dist is not None:

@@ -21,6 +21,7 @@ import torch
 
 from .cameras import CustomCam, look_at_cam2world
 from .decoder import SequentialDecoderReverse
+from .losses import fused_image_loss, image_loss_torch
 from .gaussian_model import GaussianModel
 
 
@@ -62,14 +63,18 @@ class DecoderTrainer:
 
     def __init__(self, device, n_scenes_total: int, plane_res: int = 256, plane_channels: int = 32,
                  hidden_dim: int = 128, lr: float = 9e-5, image_size: int = 512, render_fn=None, seed: int = 0,
-                 l1_weight: float = 0.2, l2_weight: float = 1.0, process_group=None, fused_activations: bool = False,
+                 l1_weight: float = 0.2, l2_weight: float = 0.1, ssim_weight: float = 0.5, sobel_weight: float = 0.2,
+                 fused_loss: bool = False, process_group=None, fused_activations: bool = False,
                  fused_decoder: bool = False):
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.pg = process_group
         self.device = torch.device(device)
         self.image_size = image_size
-        self.l1_weight, self.l2_weight = l1_weight, l2_weight
+        # loss weights: the reference's defaults (train_pano2gaussian_decoder.py:36-40); the LPIPS / identity terms need
+        # external networks and are out of scope
+        self.loss_w = dict(l1_weight=l1_weight, l2_weight=l2_weight, ssim_weight=ssim_weight, sobel_weight=sobel_weight)
+        self.fused_loss = bool(fused_loss)   # csrc/ggd_imgloss.hip instead of the torch conv graph
         torch.manual_seed(seed)
         self.decoder = SequentialDecoderReverse(plane_channels, hidden_dim).to(self.device)
         # stand-in for the finetuned GAN backbone (shared, replicated, all-reduced like the reference's G): ONE learnable
@@ -149,7 +154,7 @@ class DecoderTrainer:
             cam = CustomCam(size=self.image_size, fov=fov, extr=batch.cam2world[b])
             image = self.render_fn(cam, gs, bg_color=self.bg, **self.render_kwargs)["render"][:3]
             target = batch.target[b]
-            loss = self.l1_weight * torch.abs(image - target).mean() + self.l2_weight * ((image - target) ** 2).mean()
+            loss = (fused_image_loss if self.fused_loss else image_loss_torch)(image, target, **self.loss_w)[0]
             total = total + loss
         return total / B
 

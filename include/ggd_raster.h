@@ -263,6 +263,19 @@ size_t ggd_decoder_wgrad_floats(void);
 int ggd_decoder_wgrad(ggd_ctx* ctx, void* stream, int32_t N, const void* zbuf, const void* dzbuf, const float* dout,
                       const float* feat, const float* pos, const float* attrs, float* wgrad);
 
+/*
+ * Fused image losses of the decoder training step and their gradient (main/train_pano2gaussian_decoder.py:246-261
+ * without the external-network terms):
+ *   loss = w[0]*L1 + w[1]*L2 + w[2]*(1 - SSIM) + w[3]*Sobel
+ * with l1_loss / l2_loss / ssim of gaussian_splatting/utils/loss_utils.py:17-63 and sobel_loss of
+ * main/loss_utils/sobel_loss.py:19-30.  image, target: device [3,H,W] fp32.  weights4: HOST array of 4 floats.
+ * terms5 (device, 5 floats): L1, L2, 1 - SSIM, Sobel, weighted total.  grad_image (device [3,H,W]) = dloss/dimage.
+ * tmp: device scratch of ggd_image_loss_tmp_bytes(W, H) bytes.  Three kernel launches, no host sync.
+ */
+size_t ggd_image_loss_tmp_bytes(int32_t W, int32_t H);
+int ggd_image_loss(ggd_ctx* ctx, void* stream, int32_t W, int32_t H, const float* image, const float* target,
+                   const float* weights4, float* terms5, float* grad_image, void* tmp, size_t tmp_bytes);
+
 /* Per-stage device time (ms, hipEvent pairs on `stream`) of the most recent forward_geometry / forward_render /
  * backward call when profiling is on.  Stage names: ggd_stage_name(i), i in [0, ggd_stage_count()). */
 int ggd_set_profiling(ggd_ctx* ctx, int enabled);
