@@ -61,6 +61,27 @@ __device__ __forceinline__ float blend_exp(float x) {
   return expf(x);                   // ocml, <= 1 ulp
 }
 
+// Record-level pre-cull, done ONCE per staged record by the lane that gathers it (the per-pixel cull below costs every
+// lane of the wave ~15 instructions per record): the set {power >= thr} is the ellipse d^T Q d <= tau2 = -2 thr,
+// Q = [[A, B], [B, C]]; its axis-aligned extents are sqrt(tau2 * C / det), sqrt(tau2 * A / det).  If that box misses the
+// wave's pixel rectangle no pixel can pass the `power >= thr` test, so the record is never written to LDS.  The extents
+// are inflated by eps = 1e-3 + 4e-6 * trace^2 / det (covers the fp32 rounding of the in-loop power evaluation, whose
+// relative error grows with the anisotropy of Q) + 0.01 px; indefinite / NaN conics are kept.
+__device__ __forceinline__ bool record_box_hits(float x, float y, float A, float B, float C, float thr, float wx0,
+                                                float wx1, float wy0, float wy1) {
+  const float det = A * C - B * B;
+  const float tau2 = -2.0f * thr;
+  float ex = __builtin_huge_valf(), ey = __builtin_huge_valf();
+  if (det > 0.0f) {
+    const float s = tau2 / det;
+    const float tr = A + C;
+    const float infl = 1.001f + 4e-6f * (tr * tr) / det;
+    ex = __builtin_sqrtf(fmaxf(s * C, 0.0f)) * infl + 0.01f;
+    ey = __builtin_sqrtf(fmaxf(s * A, 0.0f)) * infl + 0.01f;
+  }
+  return !(tau2 < 0.0f) && !(x + ex < wx0 || x - ex > wx1 || y + ey < wy0 || y - ey > wy1);
+}
+
 // Wave <-> pixel mapping of the blend kernels.  PXL = pixels per lane (horizontally adjacent):
 //   PXL = 4: one wave per 16x16 tile (lane = 4x1 pixels, 4 lanes per row, 16 rows);
 //   PXL = 2: two waves per tile, each a 16x8 half (lane = 2x1 pixels, 8 lanes per row, 8 rows) -- finer culling and
@@ -121,30 +142,45 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
     if (k & 1) px[k >> 1].y = x; else px[k >> 1].x = x;
   }
 
+  // the wave's pixel rectangle (pixel centres), for the record-level pre-cull
+  constexpr int LPR = 16 / PXL, ROWS = 64 / LPR;
+  const float wx0 = (float)(g.px0 - (lane % LPR) * PXL), wx1 = wx0 + 15.0f;
+  const float wy0 = (float)(g.py - lane / LPR), wy1 = wy0 + (float)(ROWS - 1);
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+
   float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+  bool keep = false;
   auto fetch = [&](uint32_t pos) {
+    keep = false;
     if (pos < g.hi) {
       const float4* p = reinterpret_cast<const float4*>(splat + list[pos]);
       r0 = p[0]; r1 = p[1]; r2 = p[2];
-      // record slot 2 is re-used for the blend: {b, power threshold, -, -}
+      // record slot 2 is re-used for the blend: {b, power threshold, contributor index (1-based list position), -}
       const float L = logf(1.0f / (255.0f * r1.y));
       r2.y = CULL ? L - (2e-5f + 1e-6f * fabsf(L)) : -INF;
+      r2.z = __uint_as_float(pos - g.lo + 1u);
+      keep = CULL ? record_box_hits(r0.x, r0.y, r0.z, r0.w, r1.x, r2.y, wx0, wx1, wy0, wy1) : true;
     }
   };
   fetch(g.lo + lane);
   bool finished = __ballot(alive != 0) == 0ull;
   for (uint32_t base = g.lo; base < g.hi && !finished; base += 64) {
     __syncthreads();  // single-wave block: orders the previous round's LDS reads before this round's writes
-    s_rec[lane * 3 + 0] = r0; s_rec[lane * 3 + 1] = r1; s_rec[lane * 3 + 2] = r2;
+    const uint64_t kept = __ballot(keep);
+    if (keep) {  // compacted: only records whose box reaches this wave's pixels are staged
+      const int slot = __popcll(kept & lt_mask);
+      s_rec[slot * 3 + 0] = r0; s_rec[slot * 3 + 1] = r1; s_rec[slot * 3 + 2] = r2;
+    }
+    st_visited += min(64u, g.hi - base);
+    st_culled += min(64u, g.hi - base) - (uint32_t)__popcll(kept);
     fetch(base + 64 + lane);  // next round's gather is in flight while this round is blended
     __syncthreads();
-    const int n = (int)min(64u, g.hi - base);
-    const uint32_t cbase = base - g.lo;
+    const int n = __popcll(kept);
     for (int j = 0; j < n; ++j) {
       if ((j & 7) == 0 && __ballot(alive != 0) == 0ull) { finished = true; break; }
       const float4 a = s_rec[j * 3 + 0];  // x, y, conA, conB
       const float4 b = s_rec[j * 3 + 1];  // conC, opacity, r, g
-      const float2 c = *reinterpret_cast<const float2*>(&s_rec[j * 3 + 2]);  // b, power threshold
+      const float4 c = s_rec[j * 3 + 2];  // b, power threshold, contributor index
       const float dy = a.y - pyf;
       const float hA = -0.5f * a.z, nBdy = (-a.w) * dy, hCdy2 = ((-0.5f * b.x) * dy) * dy;
       const f2 gxx = {a.x, a.x};
@@ -159,14 +195,13 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
         lane_need = lane_need || need[2 * p] || need[2 * p + 1];
       }
       const uint64_t need_lanes = __ballot(lane_need);
-      st_visited += 1;
       if (need_lanes == 0ull) { st_culled += 1; continue; }
       if (stats) {
         st_lanes += (uint32_t)__popcll(need_lanes);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) st_pixels += (uint32_t)__popcll(__ballot(need[k]));
       }
-      const uint32_t contributor = cbase + (uint32_t)j + 1u;
+      const uint32_t contributor = __float_as_uint(c.z);
 #pragma unroll
       for (int k = 0; k < PXL; ++k) {
         // branch-free update (selects, no divergent control flow: the recurrence state stays in place)
@@ -289,29 +324,40 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
   for (int d = 32; d >= 1; d >>= 1) maxn = max(maxn, (uint32_t)__shfl_xor((int)maxn, d, 64));
   if (maxn == 0) return;
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+  const float twx0 = (float)(g.px0 - (lane & 3) * 4), twy0 = (float)(g.py - (lane >> 2));  // the tile's pixel rectangle
 
   uint32_t cend = g.lo + maxn;  // one past the last position that matters
   while (cend > g.lo) {
     const uint32_t cstart = (cend - g.lo > 64u) ? cend - 64u : g.lo;
     const int n = (int)(cend - cstart);
     __syncthreads();
-    uint32_t my_id = 0;
+    bool keep = false;
+    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
     if (lane < n) {
-      my_id = list[cstart + lane];
+      const uint32_t my_id = list[cstart + lane];
       const float4* p = reinterpret_cast<const float4*>(splat + my_id);
-      const float4 q1 = p[1];
-      float4 q2 = p[2];
+      q0 = p[0]; q1 = p[1]; q2 = p[2];
       const float L = logf(1.0f / (255.0f * q1.y));  // same conservative power-domain threshold as the forward
+      // record slot 2: {b, power threshold, Gaussian id, 0-based list position}
       q2.y = CULL ? L - (2e-5f + 1e-6f * fabsf(L)) : -__builtin_huge_valf();
-      s_rec[lane * 3 + 0] = p[0]; s_rec[lane * 3 + 1] = q1; s_rec[lane * 3 + 2] = q2;
+      q2.z = __uint_as_float(my_id);
+      q2.w = __uint_as_float((cstart - g.lo) + (uint32_t)lane);
+      keep = CULL ? record_box_hits(q0.x, q0.y, q0.z, q0.w, q1.x, q2.y, twx0, twx0 + 15.0f, twy0, twy0 + 15.0f) : true;
+    }
+    const uint64_t kept = __ballot(keep);
+    const int nk = __popcll(kept);
+    if (keep) {  // compacted, order preserved
+      const int slot = __popcll(kept & ((1ull << lane) - 1ull));
+      s_rec[slot * 3 + 0] = q0; s_rec[slot * 3 + 1] = q1; s_rec[slot * 3 + 2] = q2;
     }
     __syncthreads();
     uint64_t touched = 0;
-    for (int j = n - 1; j >= 0; --j) {
-      const uint32_t pos0 = (cstart - g.lo) + (uint32_t)j;  // 0-based position in the tile's list
+    for (int j = nk - 1; j >= 0; --j) {
       const float4 a = s_rec[j * 3 + 0];                                         // x, y, conA, conB
       const float4 b = s_rec[j * 3 + 1];                                         // conC, opacity, r, g
-      const float2 c2 = *reinterpret_cast<const float2*>(&s_rec[j * 3 + 2]);     // b, power threshold
+      const float4 c4 = s_rec[j * 3 + 2];                                        // b, power threshold, id, position
+      const float2 c2 = make_float2(c4.x, c4.y);
+      const uint32_t pos0 = __float_as_uint(c4.w);  // 0-based position in the tile's list
       const float col[3] = {b.z, b.w, c2.x};
       const float dy = a.y - pyf;
       const float hA = -0.5f * a.z, nBdy = (-a.w) * dy, hCdy2 = ((-0.5f * b.x) * dy) * dy;
@@ -389,9 +435,9 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
       }
     }
     __syncthreads();
-    if (lane < n && ((touched >> lane) & 1ull)) {
+    if (lane < nk && ((touched >> lane) & 1ull)) {
       const float* o = s_sum + lane * 9;
-      const size_t id = my_id;
+      const size_t id = __float_as_uint(s_rec[lane * 3 + 2].z);
       // one 48-byte accumulator record per Gaussian (GGD_ACC_*): the 9 atomics of a record land in one cache line
       float* a = grad_acc + GGD_ACC_FLOATS * id;
       atomicAdd(a + GGD_ACC_COLOR + 0, o[0]);

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_losses.py -m gpu -q 2>&1 | tail -12 | cut -c1-220
-timeout 300 python scripts/profile_train.py --fused 2>&1 | tail -1
-timeout 300 python scripts/profile_train.py --fused --torch-loss 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_raster_gpu.py tests/test_raster_backward_gpu.py -m gpu -q -x 2>&1 | tail -8 | cut -c1-220
+timeout 300 python bench.py --backward --no-train --no-decode --no-cpu-baseline --steps 100 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['stage_ms'], d['extra'])"
