@@ -86,6 +86,8 @@ extern "C" int ggd_sort_bits(int32_t W, int32_t H) {
   return 32 + (int)higher_msb(T);
 }
 
+constexpr int64_t GGD_ROWBIN_MIN_R = 1 << 20;
+
 // ---- ctx -----------------------------------------------------------------------------------------------------
 extern "C" const char* ggd_version(void) { return "ggd-raster 0.1 (gfx950)"; }
 extern "C" int ggd_stage_count(void) { return ST_COUNT; }
@@ -101,7 +103,7 @@ extern "C" ggd_ctx* ggd_create(int device) {
   if (!ctx) { ggd_fail(nullptr, GGD_E_NOMEM, "out of host memory"); return nullptr; }
   ctx->device = device;
   if (const char* e = getenv("GGD_EXP_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->opt[GGD_OPT_EXP_MODE] = v; }
-  if (const char* e = getenv("GGD_BINNING")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->opt[GGD_OPT_BINNING] = v; }
+  if (const char* e = getenv("GGD_BINNING")) { const int v = atoi(e); if (v >= 0 && v <= 3) ctx->opt[GGD_OPT_BINNING] = v; }
   if (const char* e = getenv("GGD_BLEND_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->opt[GGD_OPT_BLEND_SPLIT] = v; }
   if (const char* e = getenv("GGD_BLEND_CULL")) ctx->opt[GGD_OPT_BLEND_CULL] = atoi(e) != 0;
   int prev = 0;
@@ -136,7 +138,7 @@ extern "C" const char* ggd_last_error(ggd_ctx* ctx) { return ctx ? ctx->err.c_st
 
 extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
   if (!ctx) return GGD_E_INVALID;
-  static const int kMax[GGD_OPT_COUNT] = {2, 1, 2, 2};
+  static const int kMax[GGD_OPT_COUNT] = {2, 1, 3, 2};
   if (option < 0 || option >= GGD_OPT_COUNT || value < 0 || value > kMax[option])
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_set_option: unknown option or value");
   ctx->opt[option] = value;
@@ -311,7 +313,12 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
   const int nbits = ggd_sort_bits(prm->width, prm->height);
 
   const int bmode = ctx->opt[GGD_OPT_BINNING];
-  const bool tilebin = (bmode == 2 || (bmode == 1 && R >= (1 << 20))) && !prm->debug && ggd_tilebin_supported(T);
+  // binning path: 0 = duplicate + radix sort; 2 = single-level tile binning; 3 = two-level row/column binning;
+  // 1 = auto: row binning when the grid is <= 64 x 64 tiles (and R is past its fixed costs), else as before
+  const bool rowbin_ok = !prm->debug && ggd_rowbin_supported(prm->width, prm->height);
+  const bool rowbin = rowbin_ok && (bmode == 3 || (bmode == 1 && R >= GGD_ROWBIN_MIN_R));
+  const bool tilebin = rowbin || ((bmode == 2 || bmode == 3 || (bmode == 1 && R >= (1 << 20))) && !prm->debug &&
+                                  ggd_tilebin_supported(T));
   if (speculative && !tilebin) return ggd_fail(ctx, GGD_E_INVALID, "speculative render needs the tile-binning path");
   const uint32_t capacity = R > 0xffffffffll ? 0xffffffffu : (uint32_t)R;
   if (R > 0 && tilebin) {
@@ -319,7 +326,7 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
     const uint32_t* depth_keys = reinterpret_cast<const uint32_t*>(gb + gv.depth_keys);
     const size_t pairs = ggd_align((size_t)prm->P * sizeof(uint32_t));
     const size_t sort_tmp = ggd_sort32_tmp_bytes(prm->P);
-    const size_t bin_tmp = ggd_tilebin_tmp_bytes(prm->P, T);
+    const size_t bin_tmp = rowbin ? ggd_rowbin_tmp_bytes(prm->P, capacity) : ggd_tilebin_tmp_bytes(prm->P, T);
     rc = ggd_reserve_scratch(ctx, 4 * pairs + sort_tmp + bin_tmp, s);
     if (rc != GGD_OK) return rc;
     char* sc = static_cast<char*>(ctx->scratch);
@@ -338,7 +345,8 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
       StageTimer t(ctx, ST_DUPLICATE, s);
       // culled Gaussians carry the key 0xFFFFFFFF: their count is bin 255 of the top-digit histogram of the depth sort
       const uint32_t* culled = static_cast<const uint32_t*>(tmp) + 3 * 256 + 255;
-      rc = ggd_launch_tilebin(ctx, s, *prm, splat, tiles, va, culled, list, ranges, capacity, bin_tmp_ptr, bin_tmp);
+      rc = rowbin ? ggd_launch_rowbin(ctx, s, *prm, splat, va, culled, list, ranges, capacity, bin_tmp_ptr, bin_tmp)
+                  : ggd_launch_tilebin(ctx, s, *prm, splat, tiles, va, culled, list, ranges, capacity, bin_tmp_ptr, bin_tmp);
       if (rc != GGD_OK) return rc;
     }
   } else {
@@ -395,7 +403,9 @@ extern "C" int ggd_forward_can_speculate(ggd_ctx* ctx, const ggd_params* prm, in
   if (!ctx || !prm || prm->debug || prm->P <= 0) return 0;
   const int T = ((prm->width + 15) / 16) * ((prm->height + 15) / 16);
   const int bmode = ctx->opt[GGD_OPT_BINNING];
-  return ((bmode == 2 || (bmode == 1 && capacity >= (1 << 20))) && ggd_tilebin_supported(T)) ? 1 : 0;
+  if (ggd_rowbin_supported(prm->width, prm->height) && (bmode == 3 || (bmode == 1 && capacity >= GGD_ROWBIN_MIN_R)))
+    return 1;
+  return ((bmode == 2 || bmode == 3 || (bmode == 1 && capacity >= (1 << 20))) && ggd_tilebin_supported(T)) ? 1 : 0;
 }
 
 extern "C" int ggd_forward(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D, const float* shs,

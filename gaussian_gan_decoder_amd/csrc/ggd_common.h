@@ -85,6 +85,11 @@ int ggd_launch_sort(ggd_ctx* ctx, hipStream_t s, uint64_t* keys_a, uint32_t* val
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes);
 // Tile binning (GGD_OPT_BINNING = 1): sorted Gaussian order -> per-tile lists + ranges.
+bool ggd_rowbin_supported(int W, int H);
+size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity);
+int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat, const uint32_t* order,
+                      const uint32_t* culled_count, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
+                      size_t tmp_bytes);
 bool ggd_tilebin_supported(int T);
 size_t ggd_tilebin_tmp_bytes(int P, int T);
 int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,

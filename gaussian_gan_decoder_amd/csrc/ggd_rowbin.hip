@@ -1,0 +1,348 @@
+// ggd_rowbin.hip -- two-level stable tile binning for tile grids up to 64 x 64 (GGD_OPT_BINNING = 3 / auto).
+//
+// Same contract as ggd_tilebin.hip (stages a6-a8 as a RESULT: per tile, the Gaussians whose rect covers it in
+// (depth bits, index) order, plus ranges), from the depth-ordered Gaussians.  The single-level pass there pays O(T) LDS
+// work per 1024 Gaussians and writes one lone 4-byte store per (block, tile).  A tile rect is a product of two
+// intervals, so the expansion is split into two 1-D counting sorts with <= 64 bins each -- one bin per LANE:
+//   level 1 (rows):    Gaussian [y0, y1)  -> one entry {id, x0, x1} in the list of every tile ROW it touches
+//   level 2 (columns): row entry [x0, x1) -> the Gaussian id in the list of every TILE of that row it touches
+// Both levels are stable (items are consumed in order, chunk by chunk), so depth order survives and the final lists
+// equal the radix-sort path's bit for bit.  Per level: count (LDS difference array: +1 at lo, -1 at hi, prefix over
+// lanes), scan (one workgroup: exclusive prefix over chunks per bin, bin starts), scatter.  The scatter is
+// item-serial / bin-parallel: a wave keeps one running destination per lane (= bin); for each item the lanes in
+// [lo, hi) store and advance.  No per-tile LDS tables, no O(T) work per block, entries of one (chunk, bin) are
+// consecutive in memory.
+#include "ggd_common.h"
+
+namespace {
+
+constexpr int RB_THREADS = 256;
+constexpr int RB_WAVES = RB_THREADS / 64;
+constexpr int RB_IPL = 8;                          // items per lane
+constexpr int RB_CHUNK = RB_THREADS * RB_IPL;      // 2048 items per workgroup
+constexpr int RB_WCHUNK = 64 * RB_IPL;             // 512 items per wave
+
+// tables (uint32): [0..64] row starts (65 entries, [64] = total entries), [65..129] first level-2 block of each row
+// (+ total), [130 .. 130 + 64*64) start of every (row, column) tile list
+constexpr int RB_TAB_ROWSTART = 0, RB_TAB_ROWBLK = 65, RB_TAB_TILESTART = 130, RB_TAB_ROWINST = 130 + 64 * 64,
+              RB_TAB_FLAG = RB_TAB_ROWINST + 64, RB_TAB_WORDS = RB_TAB_FLAG + 64;
+// [ROWINST + r] instances of row r, [FLAG + r] != 0 once it is published (level-2 scan, one workgroup per row)
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// ---- level 1 count: rect of every depth-ordered Gaussian (kept, packed, for the scatter) + per-row counts of the chunk
+__global__ __launch_bounds__(RB_THREADS) void rb_count1_kernel(int W, int H, const ggd_splat* __restrict__ splat,
+                                                               const uint32_t* __restrict__ order,
+                                                               const uint32_t* __restrict__ culled_count, int P,
+                                                               uint2* __restrict__ packed, uint32_t* __restrict__ counts1) {
+  __shared__ int diff[65];
+  const uint32_t n_vis = (uint32_t)P - *culled_count;
+  const uint32_t base = (uint32_t)blockIdx.x * RB_CHUNK;
+  if (base >= n_vis) return;
+  const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+  const int tid = threadIdx.x;
+  if (tid < 65) diff[tid] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < RB_IPL; ++q) {
+    const uint32_t rnk = base + (uint32_t)q * RB_THREADS + tid;
+    if (rnk < n_vis) {
+      const uint32_t id = order[rnk];
+      const float4 a = reinterpret_cast<const float4*>(splat + id)[0];  // x, y, conA, conB
+      const float4 c = reinterpret_cast<const float4*>(splat + id)[2];  // b, depth, radius, tiles
+      int x0, y0, x1, y1;
+      const int n = ggd_tile_rect(a.x, a.y, __float_as_int(c.z), gx, gy, x0, y0, x1, y1);
+      if (n <= 0) { x0 = x1 = y0 = y1 = 0; }
+      packed[rnk] = make_uint2(id, (uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16) | ((uint32_t)y1 << 24));
+      if (n > 0) { atomicAdd(&diff[y0], 1); atomicAdd(&diff[y1], -1); }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) counts1[(size_t)blockIdx.x * 64 + tid] = (uint32_t)wave_incl_scan_i32(diff[tid]);
+}
+
+// ---- scan over chunks, one workgroup, lane = bin: counts[c][bin] -> exclusive prefix within the bin; totals per bin
+//      level 1: rows of one segment (all chunks);   level 2 is handled per row in rb_scan2_kernel.
+__global__ __launch_bounds__(1024) void rb_scan1_kernel(uint32_t* __restrict__ counts1,
+                                                        const uint32_t* __restrict__ culled_count, int P,
+                                                        uint32_t* __restrict__ tab) {
+  __shared__ uint32_t part[16][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t n_vis = (uint32_t)P - *culled_count;
+  const int nb = (int)((n_vis + RB_CHUNK - 1) / RB_CHUNK);
+  const int per = (nb + 15) / 16;
+  const int r0 = min(nb, wv * per), r1 = min(nb, r0 + per);
+  uint32_t s = 0;
+#pragma unroll 8
+  for (int r = r0; r < r1; ++r) s += counts1[(size_t)r * 64 + lane];
+  part[wv][lane] = s;
+  __syncthreads();
+  uint32_t run = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { const uint32_t p = part[w][lane]; if (w < wv) run += p; tot += p; }
+#pragma unroll 8
+  for (int r = r0; r < r1; ++r) {
+    const size_t idx = (size_t)r * 64 + lane;
+    const uint32_t c = counts1[idx];
+    counts1[idx] = run;
+    run += c;
+  }
+  if (wv == 0) {
+    const uint32_t inc = wave_incl_scan_u32(tot);
+    tab[RB_TAB_ROWSTART + lane] = inc - tot;
+    if (lane == 63) tab[RB_TAB_ROWSTART + 64] = inc;
+    const uint32_t nblk = (tot + RB_CHUNK - 1) / RB_CHUNK;
+    const uint32_t binc = wave_incl_scan_u32(nblk);
+    tab[RB_TAB_ROWBLK + lane] = binc - nblk;
+    if (lane == 63) tab[RB_TAB_ROWBLK + 64] = binc;
+    tab[RB_TAB_FLAG + lane] = 0u;   // consumed by rb_scan2_kernel (next launch on the stream)
+  }
+}
+
+// Per-wave bin counts of up to RB_WCHUNK items held RB_IPL per lane: LDS difference array + prefix over lanes.
+__device__ __forceinline__ uint32_t wave_bin_counts(int* diff /*[65], zeroed*/, const uint32_t (&iv)[RB_IPL]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < RB_IPL; ++q) {
+    const uint32_t lo = iv[q] & 0xffu, hi = iv[q] >> 8;
+    if (hi > lo) { atomicAdd(&diff[lo], 1); atomicAdd(&diff[hi], -1); }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  return (uint32_t)wave_incl_scan_i32(diff[lane]);
+}
+
+// Item-serial / bin-parallel emission of one wave's items.  dst = running destination of bin `lane`.
+// iv = lo | hi << 8 (0 for padding items: no lane is active).  The loop always runs the full 64 items of a batch,
+// unrolled by 8, so the readlanes of 8 items issue back to back (the only loop-carried dependence is dst).
+template <bool TWO, typename Emit>
+__device__ __forceinline__ void wave_emit(const uint32_t (&iv)[RB_IPL], const uint32_t (&pa)[RB_IPL],
+                                          const uint32_t (&pb)[RB_IPL], int n_items, uint32_t& dst, Emit&& emit) {
+  const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < RB_IPL; ++q) {
+    if (q * 64 >= n_items) break;
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) {
+      const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)iv[q], j);
+      const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)pa[q], j);
+      const uint32_t b = TWO ? (uint32_t)__builtin_amdgcn_readlane((int)pb[q], j) : 0u;
+      const uint32_t l = v & 0xffu, w = (v >> 8) - l;   // scalar
+      if (lane - l < w) { emit(dst, a, b); dst += 1; }
+    }
+  }
+}
+
+// ---- level 1 scatter: {id, x0 | x1 << 8} into the list of every row in [y0, y1)
+__global__ __launch_bounds__(RB_THREADS) void rb_scatter1_kernel(const uint2* __restrict__ packed,
+                                                                 const uint32_t* __restrict__ culled_count, int P,
+                                                                 const uint32_t* __restrict__ prefix1,
+                                                                 const uint32_t* __restrict__ tab,
+                                                                 uint2* __restrict__ ent, uint32_t ent_cap) {
+  __shared__ int diff[RB_WAVES][65];
+  __shared__ uint32_t wcnt[RB_WAVES][64];
+  const uint32_t n_vis = (uint32_t)P - *culled_count;
+  const uint32_t base = (uint32_t)blockIdx.x * RB_CHUNK;
+  if (base >= n_vis) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int i = tid; i < RB_WAVES * 65; i += RB_THREADS) (&diff[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t wbeg = base + (uint32_t)wv * RB_WCHUNK;
+  const int n_items = (int)min((uint32_t)RB_WCHUNK, n_vis > wbeg ? n_vis - wbeg : 0u);
+  uint32_t iv[RB_IPL], pa[RB_IPL], pb[RB_IPL];
+#pragma unroll
+  for (int q = 0; q < RB_IPL; ++q) {
+    const int i = q * 64 + lane;
+    uint2 it = make_uint2(0, 0);
+    if (i < n_items) it = packed[wbeg + i];
+    pa[q] = it.x; pb[q] = it.y & 0xffffu;
+    iv[q] = it.y >> 16;   // y0 | y1 << 8
+  }
+  const uint32_t mine = wave_bin_counts(diff[wv], iv);
+  wcnt[wv][lane] = mine;
+  __syncthreads();
+  uint32_t dst = tab[RB_TAB_ROWSTART + lane] + prefix1[(size_t)blockIdx.x * 64 + lane];
+#pragma unroll
+  for (int w = 0; w < RB_WAVES; ++w) if (w < wv) dst += wcnt[w][lane];
+  wave_emit<true>(iv, pa, pb, n_items, dst, [&](uint32_t d, uint32_t id, uint32_t xx) {
+    if (d < ent_cap) ent[d] = make_uint2(id, xx);
+  });
+}
+
+// level-2 block -> (row, chunk within the row)
+__device__ __forceinline__ bool rb_block_row(const uint32_t* __restrict__ tab, uint32_t blk, int& row, uint32_t& chunk) {
+  if (blk >= tab[RB_TAB_ROWBLK + 64]) return false;
+  int r = 0;
+#pragma unroll
+  for (int step = 32; step >= 1; step >>= 1)
+    if (tab[RB_TAB_ROWBLK + r + step] <= blk) r += step;
+  row = r; chunk = blk - tab[RB_TAB_ROWBLK + r];
+  return true;
+}
+
+__global__ __launch_bounds__(RB_THREADS) void rb_count2_kernel(const uint2* __restrict__ ent, uint32_t ent_cap,
+                                                               const uint32_t* __restrict__ tab,
+                                                               uint32_t* __restrict__ counts2) {
+  __shared__ int diff[65];
+  int row; uint32_t chunk;
+  if (!rb_block_row(tab, blockIdx.x, row, chunk)) return;
+  const int tid = threadIdx.x;
+  if (tid < 65) diff[tid] = 0;
+  __syncthreads();
+  const uint32_t rbeg = tab[RB_TAB_ROWSTART + row], rend = min(tab[RB_TAB_ROWSTART + row + 1], ent_cap);
+  const uint32_t base = rbeg + chunk * RB_CHUNK;
+#pragma unroll
+  for (int q = 0; q < RB_IPL; ++q) {
+    const uint32_t i = base + (uint32_t)q * RB_THREADS + tid;
+    if (i < rend) {
+      const uint32_t xx = ent[i].y;
+      const uint32_t x0 = xx & 0xffu, x1 = (xx >> 8) & 0xffu;
+      if (x1 > x0) { atomicAdd(&diff[x0], 1); atomicAdd(&diff[x1], -1); }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) counts2[(size_t)blockIdx.x * 64 + tid] = (uint32_t)wave_incl_scan_i32(diff[tid]);
+}
+
+// ---- level-2 scan, one workgroup per tile row: exclusive prefix over the row's chunks (lane = column, 16 waves split
+//      the chunks), tile totals, then the start of every tile list.  The only cross-row quantity is the number of
+//      instances in the rows above: every workgroup publishes its row total (release) and sums the totals of the lower
+//      rows (relaxed poll + acquire).  Workgroups only ever wait for lower-numbered ones.
+__global__ __launch_bounds__(1024) void rb_scan2_kernel(uint32_t* __restrict__ counts2, uint32_t* tab, int gx, int gy,
+                                                        uint32_t* __restrict__ ranges) {
+  __shared__ uint32_t part[16][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = blockIdx.x;
+  const uint32_t b0 = tab[RB_TAB_ROWBLK + r], b1 = tab[RB_TAB_ROWBLK + r + 1];
+  const uint32_t nb = b1 - b0, per = (nb + 15u) / 16u;
+  const uint32_t c0 = b0 + min(nb, (uint32_t)wv * per), c1 = min(b1, c0 + per);
+  uint32_t s = 0;
+#pragma unroll 4
+  for (uint32_t b = c0; b < c1; ++b) s += counts2[(size_t)b * 64 + lane];
+  part[wv][lane] = s;
+  __syncthreads();
+  uint32_t run = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { const uint32_t p = part[w][lane]; if (w < wv) run += p; tot += p; }
+#pragma unroll 4
+  for (uint32_t b = c0; b < c1; ++b) {
+    const size_t idx = (size_t)b * 64 + lane;
+    const uint32_t c = counts2[idx];
+    counts2[idx] = run;
+    run += c;
+  }
+  if (wv == 0) {
+    const uint32_t inc = wave_incl_scan_u32(tot);
+    if (lane == 63) {
+      tab[RB_TAB_ROWINST + r] = inc;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_store(&tab[RB_TAB_FLAG + r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t below = 0;
+    if (lane < r) {
+      while (__hip_atomic_load(&tab[RB_TAB_FLAG + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {}
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (lane < r) below = __hip_atomic_load(&tab[RB_TAB_ROWINST + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t binc = wave_incl_scan_u32(below);
+    const uint32_t rowbase = (uint32_t)__builtin_amdgcn_readlane((int)binc, 63);
+    if (lane < gx) {
+      const uint32_t start = rowbase + inc - tot;
+      tab[RB_TAB_TILESTART + r * 64 + lane] = start;
+      const int t = r * gx + lane;
+      ranges[2 * t] = tot ? start : 0u;
+      ranges[2 * t + 1] = tot ? start + tot : 0u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(RB_THREADS) void rb_scatter2_kernel(const uint2* __restrict__ ent, uint32_t ent_cap,
+                                                                 const uint32_t* __restrict__ tab,
+                                                                 const uint32_t* __restrict__ prefix2,
+                                                                 uint32_t* __restrict__ list, uint32_t capacity) {
+  __shared__ int diff[RB_WAVES][65];
+  __shared__ uint32_t wcnt[RB_WAVES][64];
+  int row; uint32_t chunk;
+  if (!rb_block_row(tab, blockIdx.x, row, chunk)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int i = tid; i < RB_WAVES * 65; i += RB_THREADS) (&diff[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t rbeg = tab[RB_TAB_ROWSTART + row], rend = min(tab[RB_TAB_ROWSTART + row + 1], ent_cap);
+  const uint32_t wbeg = rbeg + chunk * RB_CHUNK + (uint32_t)wv * RB_WCHUNK;
+  const int n_items = (int)min((uint32_t)RB_WCHUNK, rend > wbeg ? rend - wbeg : 0u);
+  uint32_t iv[RB_IPL], pa[RB_IPL], pb[RB_IPL];
+#pragma unroll
+  for (int q = 0; q < RB_IPL; ++q) {
+    const int i = q * 64 + lane;
+    uint2 it = make_uint2(0, 0);
+    if (i < n_items) it = ent[wbeg + i];
+    pa[q] = it.x; pb[q] = 0;
+    iv[q] = it.y & 0xffffu;   // x0 | x1 << 8
+  }
+  const uint32_t mine = wave_bin_counts(diff[wv], iv);
+  wcnt[wv][lane] = mine;
+  __syncthreads();
+  uint32_t dst = tab[RB_TAB_TILESTART + row * 64 + lane] + prefix2[(size_t)blockIdx.x * 64 + lane];
+#pragma unroll
+  for (int w = 0; w < RB_WAVES; ++w) if (w < wv) dst += wcnt[w][lane];
+  wave_emit<false>(iv, pa, pb, n_items, dst, [&](uint32_t d, uint32_t id, uint32_t) {
+    if (d < capacity) list[d] = id;
+  });
+}
+
+static inline int rb_blocks1(int P) { return (P + RB_CHUNK - 1) / RB_CHUNK; }
+static inline uint32_t rb_blocks2(uint32_t cap) { return (cap + RB_CHUNK - 1) / RB_CHUNK + 64; }
+
+}  // namespace
+
+bool ggd_rowbin_supported(int W, int H) { return W > 0 && H > 0 && (W + 15) / 16 <= 64 && (H + 15) / 16 <= 64; }
+
+size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity) {
+  return ggd_align((size_t)P * sizeof(uint2)) + ggd_align((size_t)rb_blocks1(P) * 64 * 4) +
+         ggd_align((size_t)RB_TAB_WORDS * 4) + ggd_align((size_t)capacity * sizeof(uint2)) +
+         ggd_align((size_t)rb_blocks2(capacity) * 64 * 4);
+}
+
+// capacity: upper bound on num_rendered (the level-1 entry count is <= num_rendered); order = depth-sorted ids.
+int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat, const uint32_t* order,
+                      const uint32_t* culled_count, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
+                      size_t tmp_bytes) {
+  if (!ggd_rowbin_supported(prm.width, prm.height)) return ggd_fail(ctx, GGD_E_INVALID, "tile grid too large for row binning");
+  if (tmp_bytes < ggd_rowbin_tmp_bytes(prm.P, capacity)) return ggd_fail(ctx, GGD_E_INVALID, "rowbin tmp too small");
+  const int gx = (prm.width + 15) / 16, gy = (prm.height + 15) / 16;
+  char* p = static_cast<char*>(tmp);
+  uint2* packed = reinterpret_cast<uint2*>(p); p += ggd_align((size_t)prm.P * sizeof(uint2));
+  uint32_t* counts1 = reinterpret_cast<uint32_t*>(p); p += ggd_align((size_t)rb_blocks1(prm.P) * 64 * 4);
+  uint32_t* tab = reinterpret_cast<uint32_t*>(p); p += ggd_align((size_t)RB_TAB_WORDS * 4);
+  uint2* ent = reinterpret_cast<uint2*>(p); p += ggd_align((size_t)capacity * sizeof(uint2));
+  uint32_t* counts2 = reinterpret_cast<uint32_t*>(p);
+  const int nb1 = rb_blocks1(prm.P);
+  const uint32_t nb2 = rb_blocks2(capacity);
+  hipLaunchKernelGGL(rb_count1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, prm.width, prm.height, splat, order,
+                     culled_count, prm.P, packed, counts1);
+  hipLaunchKernelGGL(rb_scan1_kernel, dim3(1), dim3(1024), 0, s, counts1, culled_count, prm.P, tab);
+  hipLaunchKernelGGL(rb_scatter1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, packed, culled_count, prm.P, counts1, tab,
+                     ent, capacity);
+  hipLaunchKernelGGL(rb_count2_kernel, dim3(nb2), dim3(RB_THREADS), 0, s, ent, capacity, tab, counts2);
+  hipLaunchKernelGGL(rb_scan2_kernel, dim3(gy), dim3(1024), 0, s, counts2, tab, gx, gy, ranges);
+  hipLaunchKernelGGL(rb_scatter2_kernel, dim3(nb2), dim3(RB_THREADS), 0, s, ent, capacity, tab, counts2, list, capacity);
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}

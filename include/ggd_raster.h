@@ -192,7 +192,9 @@ enum {
   GGD_OPT_BINNING = 2,    /* how the per-tile sorted lists are built (results are identical):
                              0 = duplicateWithKeys + 64-bit (tile|depth) radix sort + identifyTileRanges,
                              2 = depth-sort the Gaussians once, then ONE stable tile-binning pass,
-                             1 (default) = auto: 2 when num_rendered >= 2^20 (where it is faster), else 0.
+                             3 = depth-sort, then TWO 1-D stable binning passes (tile rows, then columns; grids up
+                                 to 64 x 64 tiles, falls back to 2 beyond),
+                             1 (default) = auto: 3 (or 2 on larger grids) when num_rendered >= 2^20, else 0.
                              debug=1 (key taps) or a tile grid beyond the LDS budget always uses 0 */
   GGD_OPT_BLEND_SPLIT = 3, /* forward blend: 0 = one wave per 16x16 tile (4 px/lane), 2 = two waves per tile (16x8
                              halves, 2 px/lane), 1 (default) = auto */

@@ -78,6 +78,12 @@ def test_forward_stages_match_oracle(native_lib, case):
     np.testing.assert_array_equal(n2["point_list"], o["point_list"])
     np.testing.assert_array_equal(n2["n_contrib"], n["n_contrib"])
     np.testing.assert_array_equal(n2["color"].cpu().numpy(), color)
+    # ---- and so must the two-level row / column binning (GGD_OPT_BINNING = 3)
+    n3 = run_native(d, debug=False, binning=3)
+    assert n3["num_rendered"] == o["num_rendered"]
+    np.testing.assert_array_equal(n3["ranges"], o["ranges"])
+    np.testing.assert_array_equal(n3["point_list"], o["point_list"])
+    np.testing.assert_array_equal(n3["color"].cpu().numpy(), color)
 
 
 def test_empty_and_all_culled(native_lib):
