@@ -86,7 +86,7 @@ extern "C" int ggd_sort_bits(int32_t W, int32_t H) {
   return 32 + (int)higher_msb(T);
 }
 
-constexpr int64_t GGD_ROWBIN_MIN_R = 1 << 20;
+constexpr int64_t GGD_ROWBIN_MIN_R = 3 << 18;   // measured crossover against the radix-sort path (~0.7 M instances)
 
 // ---- ctx -----------------------------------------------------------------------------------------------------
 extern "C" const char* ggd_version(void) { return "ggd-raster 0.1 (gfx950)"; }
