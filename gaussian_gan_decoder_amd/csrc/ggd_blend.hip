@@ -61,6 +61,20 @@ __device__ __forceinline__ float blend_exp(float x) {
   return expf(x);                   // ocml, <= 1 ulp
 }
 
+// Two exps per call; MODE 2 is the same arithmetic as blend_exp<2> per component, with the multiplies / FMAs packed.
+template <int MODE>
+__device__ __forceinline__ f2 blend_exp2v(f2 x) {
+  if (MODE == 2) {
+    const f2 L2E = {1.44269502162933349609375f, 1.44269502162933349609375f};
+    const f2 t = x * L2E;
+    f2 lo = __builtin_elementwise_fma(x, L2E, -t);
+    lo = __builtin_elementwise_fma(x, (f2){1.925963033500011e-08f, 1.925963033500011e-08f}, lo);
+    const f2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    return __builtin_elementwise_fma(e, lo * 0.693147182464599609375f, e);
+  }
+  return (f2){blend_exp<MODE>(x.x), blend_exp<MODE>(x.y)};
+}
+
 // Record-level pre-cull, done ONCE per staged record by the lane that gathers it (the per-pixel cull below costs every
 // lane of the wave ~15 instructions per record): the set {power >= thr} is the ellipse d^T Q d <= tau2 = -2 thr,
 // Q = [[A, B], [B, C]]; its axis-aligned extents are sqrt(tau2 * C / det), sqrt(tau2 * A / det).  If that box misses the
@@ -127,14 +141,14 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
   const bool row_in = g.py < H;
   const float INF = __builtin_huge_valf();
   uint32_t st_visited = 0, st_culled = 0, st_lanes = 0, st_pixels = 0;  // wave-uniform debug counters (GGD stats)
-  float Tr[PXL], C[PXL][3];
+  f2 Tr[NP], C[NP][3];  // per pixel PAIR: transmittance, accumulated colour
   uint32_t last[PXL];
   f2 px[NP];  // pixel x coordinates; +inf once the pixel is finished / outside the image
   int alive = 0;
   const float pyf = (float)g.py;
 #pragma unroll
   for (int k = 0; k < PXL; ++k) {
-    Tr[k] = 1.0f; C[k][0] = C[k][1] = C[k][2] = 0.0f;
+    if (k & 1) { Tr[k >> 1] = (f2){1.0f, 1.0f}; C[k >> 1][0] = C[k >> 1][1] = C[k >> 1][2] = (f2){0.0f, 0.0f}; }
     last[k] = 0;
     const bool in = row_in && (g.px0 + k) < W;
     alive += in ? 1 : 0;
@@ -203,22 +217,29 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
       }
       const uint32_t contributor = __float_as_uint(c.z);
 #pragma unroll
-      for (int k = 0; k < PXL; ++k) {
-        // branch-free update (selects, no divergent control flow: the recurrence state stays in place)
-        const float power = (k & 1) ? pw[k >> 1].y : pw[k >> 1].x;
-        const float alpha = fminf(0.99f, b.y * blend_exp<EXP_MODE>(power));
-        const bool live = need[k] && !(power > 0.0f) && !(alpha < ALPHA_FLOOR);
-        const float test_T = Tr[k] * (1.0f - alpha);
-        const bool stop = live && (test_T < 0.0001f);
-        const bool upd = live && !(test_T < 0.0001f);
-        const float i0 = b.z * alpha * Tr[k], i1 = b.w * alpha * Tr[k], i2 = c.x * alpha * Tr[k];
-        C[k][0] += upd ? i0 : 0.0f;
-        C[k][1] += upd ? i1 : 0.0f;
-        C[k][2] += upd ? i2 : 0.0f;
-        Tr[k] = upd ? test_T : Tr[k];
-        last[k] = upd ? contributor : last[k];
-        if (k & 1) px[k >> 1].y = stop ? INF : px[k >> 1].y; else px[k >> 1].x = stop ? INF : px[k >> 1].x;
-        alive -= stop ? 1 : 0;
+      for (int p = 0; p < NP; ++p) {
+        // branch-free, packed update of a pixel pair.  alpha, the thresholds and T <- T (1 - alpha) are evaluated
+        // exactly as published; the colour is accumulated as fma(col, alpha * T, C) (one rounding fewer than
+        // (col * alpha) * T + C -- inside the 1e-5 tolerance, three packed FMAs for the pair instead of 18 scalar ops).
+        const f2 G = blend_exp2v<EXP_MODE>(pw[p]);
+        const f2 av = G * b.y;
+        const f2 alpha = {fminf(0.99f, av.x), fminf(0.99f, av.y)};
+        const bool live0 = need[2 * p] && !(pw[p].x > 0.0f) && !(alpha.x < ALPHA_FLOOR);
+        const bool live1 = need[2 * p + 1] && !(pw[p].y > 0.0f) && !(alpha.y < ALPHA_FLOOR);
+        const f2 test_T = Tr[p] * ((f2){1.0f, 1.0f} - alpha);
+        const bool low0 = test_T.x < 0.0001f, low1 = test_T.y < 0.0001f;
+        const bool stop0 = live0 && low0, stop1 = live1 && low1;
+        const bool upd0 = live0 && !low0, upd1 = live1 && !low1;
+        const f2 aT = alpha * Tr[p];
+        const f2 w = {upd0 ? aT.x : 0.0f, upd1 ? aT.y : 0.0f};
+        C[p][0] = __builtin_elementwise_fma((f2){b.z, b.z}, w, C[p][0]);
+        C[p][1] = __builtin_elementwise_fma((f2){b.w, b.w}, w, C[p][1]);
+        C[p][2] = __builtin_elementwise_fma((f2){c.x, c.x}, w, C[p][2]);
+        Tr[p] = (f2){upd0 ? test_T.x : Tr[p].x, upd1 ? test_T.y : Tr[p].y};
+        last[2 * p] = upd0 ? contributor : last[2 * p];
+        last[2 * p + 1] = upd1 ? contributor : last[2 * p + 1];
+        px[p] = (f2){stop0 ? INF : px[p].x, stop1 ? INF : px[p].y};
+        alive -= (stop0 ? 1 : 0) + (stop1 ? 1 : 0);
       }
     }
   }
@@ -236,33 +257,37 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
   const size_t pix0 = (size_t)g.py * W + g.px0;
   if (g.px0 + PXL - 1 < W && (W & 3) == 0) {
     if constexpr (PXL == 4) {
-      *reinterpret_cast<float4*>(final_T + pix0) = make_float4(Tr[0], Tr[1], Tr[2], Tr[3]);
+      *reinterpret_cast<float4*>(final_T + pix0) = make_float4(Tr[0].x, Tr[0].y, Tr[NP - 1].x, Tr[NP - 1].y);
       *reinterpret_cast<uint4*>(n_contrib + pix0) = make_uint4(last[0], last[1], last[2], last[3]);
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         const float bgc = ch == 0 ? bg0 : (ch == 1 ? bg1 : bg2);
         *reinterpret_cast<float4*>(out_color + ch * HW + pix0) = make_float4(
-            C[0][ch] + Tr[0] * bgc, C[1][ch] + Tr[1] * bgc, C[2][ch] + Tr[2] * bgc, C[3][ch] + Tr[3] * bgc);
+            C[0][ch].x + Tr[0].x * bgc, C[0][ch].y + Tr[0].y * bgc, C[NP - 1][ch].x + Tr[NP - 1].x * bgc,
+            C[NP - 1][ch].y + Tr[NP - 1].y * bgc);
       }
     } else {
-      *reinterpret_cast<float2*>(final_T + pix0) = make_float2(Tr[0], Tr[1]);
+      *reinterpret_cast<float2*>(final_T + pix0) = make_float2(Tr[0].x, Tr[0].y);
       *reinterpret_cast<uint2*>(n_contrib + pix0) = make_uint2(last[0], last[1]);
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         const float bgc = ch == 0 ? bg0 : (ch == 1 ? bg1 : bg2);
         *reinterpret_cast<float2*>(out_color + ch * HW + pix0) =
-            make_float2(C[0][ch] + Tr[0] * bgc, C[1][ch] + Tr[1] * bgc);
+            make_float2(C[0][ch].x + Tr[0].x * bgc, C[0][ch].y + Tr[0].y * bgc);
       }
     }
   } else {
 #pragma unroll
     for (int k = 0; k < PXL; ++k) {
       if (g.px0 + k < W) {
-        final_T[pix0 + k] = Tr[k];
+        const float Tk = (k & 1) ? Tr[k >> 1].y : Tr[k >> 1].x;
+        const float c0 = (k & 1) ? C[k >> 1][0].y : C[k >> 1][0].x, c1 = (k & 1) ? C[k >> 1][1].y : C[k >> 1][1].x,
+                    c2 = (k & 1) ? C[k >> 1][2].y : C[k >> 1][2].x;
+        final_T[pix0 + k] = Tk;
         n_contrib[pix0 + k] = last[k];
-        out_color[pix0 + k] = C[k][0] + Tr[k] * bg0;
-        out_color[HW + pix0 + k] = C[k][1] + Tr[k] * bg1;
-        out_color[2 * HW + pix0 + k] = C[k][2] + Tr[k] * bg2;
+        out_color[pix0 + k] = c0 + Tk * bg0;
+        out_color[HW + pix0 + k] = c1 + Tk * bg1;
+        out_color[2 * HW + pix0 + k] = c2 + Tk * bg2;
       }
     }
   }

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 | cut -c1-220
-timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; python -c "
-import json; d=json.load(open('gpurun_out/bench.json')); print(d['value'], d['stage_ms']); print(d['decode_render']['frames_per_s'], d['train']['ms_per_iter'], d['train_fused_decoder']['ms_per_iter'])"
+timeout 900 python -m pytest tests/test_raster_gpu.py -m gpu -q -x 2>&1 | tail -4 | cut -c1-220
+timeout 300 python bench.py --no-train --no-decode --no-cpu-baseline --steps 100 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['stage_ms'])"
