@@ -212,6 +212,7 @@ constexpr int RS_BINS = 256;
 constexpr int RS_MAX_PASSES = 8;
 constexpr int RS32_ITEMS = 16;                   // tile size of the 32-bit (depth) sort (4 was slower: longer look-back)
 constexpr int RS32_TILE = RS_THREADS * RS32_ITEMS;
+constexpr int RS_LOOKBACK = 8;   // predecessors examined per round trip of the decoupled look-back
 constexpr uint32_t RS_FLAG_LOCAL = 1u << 30, RS_FLAG_INCL = 2u << 30, RS_COUNT_MASK = (1u << 30) - 1u;
 
 __device__ __forceinline__ uint32_t rs_load(uint32_t* p) {
@@ -317,11 +318,11 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
       int64_t t = (int64_t)tile - 1;
       bool done = false;
       while (!done) {
-        uint32_t v[8];
+        uint32_t v[RS_LOOKBACK];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (t - i >= 0) ? rs_load(status + (size_t)(t - i) * RS_BINS + d) : RS_FLAG_INCL;
+        for (int i = 0; i < RS_LOOKBACK; ++i) v[i] = (t - i >= 0) ? rs_load(status + (size_t)(t - i) * RS_BINS + d) : RS_FLAG_INCL;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < RS_LOOKBACK; ++i) {
           if (!done) {
             uint32_t x = v[i];
             if ((x >> 30) == 0u) {  // not published yet: poll this one
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
             if ((x >> 30) == 2u) done = true;
           }
         }
-        t -= 8;
+        t -= RS_LOOKBACK;
       }
       rs_store(my, RS_FLAG_INCL | (excl + local));
     }
