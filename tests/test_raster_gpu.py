@@ -103,7 +103,8 @@ def test_empty_and_all_culled(native_lib):
     np.testing.assert_array_equal(n["color"].cpu().numpy(), o["color"])
 
 
-def test_single_call_forward_capacity_overflow_is_retried(native_lib):
+@pytest.mark.parametrize("path", [2, 3], ids=["tilebin", "rowbin"])
+def test_single_call_forward_capacity_overflow_is_retried(native_lib, path):
     """The torch wrapper sizes the binning buffer of the single-call (speculative) forward from the previous frame of
     the same shape; when the next frame needs more (GGD_E_CAPACITY) it must transparently re-run with an exact buffer."""
     from gaussian_gan_decoder_amd import _capi
@@ -112,16 +113,16 @@ def test_single_call_forward_capacity_overflow_is_retried(native_lib):
     big = scene_inputs(P=6000, size=128, lsm=-2.0, seed=11)         # same shape, >> 1.25x + 64k instances
     ctx = _capi.context_for(dev)
     ctx.capacity_hint.pop((6000, 128, 128), None)
-    n_small = run_native(small, debug=False, binning=2)             # first call: two-phase, records the hint
+    n_small = run_native(small, debug=False, binning=path)             # first call: two-phase, records the hint
     assert ctx.capacity_hint[(6000, 128, 128)] == n_small["num_rendered"]
     o_big = run_oracle(big)
     assert o_big["num_rendered"] > 1.25 * n_small["num_rendered"] + 65536          # really overflows the hint
-    n_big = run_native(big, debug=False, binning=2)                 # speculative -> overflow -> exact retry
+    n_big = run_native(big, debug=False, binning=path)                 # speculative -> overflow -> exact retry
     assert n_big["num_rendered"] == o_big["num_rendered"]
     np.testing.assert_array_equal(n_big["point_list"], o_big["point_list"])
     np.testing.assert_array_equal(n_big["ranges"], o_big["ranges"])
     assert np.abs(n_big["color"].cpu().numpy() - o_big["color"]).max() <= 1e-4
-    n_big2 = run_native(big, debug=False, binning=2)                # now the hint fits: speculative path succeeds
+    n_big2 = run_native(big, debug=False, binning=path)                # now the hint fits: speculative path succeeds
     np.testing.assert_array_equal(n_big2["point_list"], o_big["point_list"])
     np.testing.assert_array_equal(n_big2["color"].cpu().numpy(), n_big["color"].cpu().numpy())
 
