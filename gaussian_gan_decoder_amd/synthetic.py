@@ -49,6 +49,16 @@ class SyntheticScene:
     def opacities(self):
         return torch.sigmoid(self.opacity_logit)
 
+    def gaussian_model(self, requires_grad: bool = False):
+        """The scene as the reference's container class (`GaussianModel(0)` with raw, pre-activation attributes, as
+        main/train_pano2gaussian_decoder.py:215-227 fills it)."""
+        from .gaussian_model import GaussianModel
+        pc = GaussianModel(0)
+        mk = (lambda t: t.clone().requires_grad_(True)) if requires_grad else (lambda t: t)
+        pc._xyz, pc._scaling, pc._rotation = mk(self.xyz), mk(self.log_scales), mk(self.rot_raw)
+        pc._opacity, pc._features_dc = mk(self.opacity_logit), mk(self.features_dc)
+        return pc
+
     def to(self, device):
         cam = make_camera(self.size, self.cam._fov_deg, self.cam._h, self.cam._v, device=device)
         return SyntheticScene(self.xyz.to(device), self.log_scales.to(device), self.rot_raw.to(device),
