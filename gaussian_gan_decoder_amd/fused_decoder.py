@@ -167,6 +167,40 @@ class FusedDecoderFn(torch.autograd.Function):
         return (dfeat, None, None, None, *grads)
 
 
+class _SplitAttrs(torch.autograd.Function):
+    """attrs[B,N,16] -> per scene the five contiguous tensors the rasterizer takes (xyz, scale, rotation, opacity,
+    colour).  One autograd node: the backward writes the 5*B incoming gradients straight into one [B,N,16] buffer instead
+    of autograd's chain of select / slice backward nodes (each of which zero-fills a full-size tensor and adds it)."""
+    COLS = ((11, 14), (8, 11), (4, 8), (3, 4), (0, 3))   # xyz, scale, rotation, opacity, colour
+
+    @staticmethod
+    def forward(ctx, attrs):
+        ctx.shape = attrs.shape
+        return tuple(attrs[b, :, lo:hi].contiguous() for b in range(attrs.shape[0]) for lo, hi in _SplitAttrs.COLS)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        B, N, _ = ctx.shape
+        g0 = next(g for g in grads if g is not None)
+        d = torch.empty(ctx.shape, dtype=g0.dtype, device=g0.device)
+        d[:, :, 14:16] = 0
+        k = 0
+        for b in range(B):
+            for lo, hi in _SplitAttrs.COLS:
+                if grads[k] is None:
+                    d[b, :, lo:hi] = 0
+                else:
+                    d[b, :, lo:hi] = grads[k]
+                k += 1
+        return d
+
+
+def split_attrs(attrs: torch.Tensor):
+    """[(xyz, scale, rotation, opacity, colour)] * B from the fused decoder's attrs[B,N,16] (see _SplitAttrs)."""
+    flat = _SplitAttrs.apply(attrs)
+    return [flat[5 * b:5 * b + 5] for b in range(attrs.shape[0])]
+
+
 class FusedTrainDecoder(torch.nn.Module):
     """Training front-end with the `SequentialDecoderReverse` call signature: tri-plane gather (HIP) + the fused
     bf16-MFMA decoder with autograd.  Wraps (and shares the parameters of) a SequentialDecoderReverse."""

@@ -53,7 +53,7 @@ def make_scene_batch(scene_ids, n_points: int, size: int, device, seed: int = 0)
         blob = torch.exp(-(xx ** 2 + yy ** 2) * 3.0)
         col = torch.rand(3, generator=g)
         tgt.append(0.5 + (col[:, None, None] - 0.5) * blob[None])
-    return SceneBatch(torch.stack(pos).to(device), torch.stack(c2w).to(device), torch.tensor(fov),
+    return SceneBatch(torch.stack(pos).to(device), torch.stack(c2w), torch.tensor(fov),
                       torch.stack(tgt).to(device), torch.tensor(list(scene_ids)))
 
 
@@ -137,21 +137,25 @@ class DecoderTrainer:
         scene_ids = batch.scene_id.tolist()
         attrs = None
         if self.fused_decoder:   # all local scenes through one decoder launch
-            attrs = self.decoder_fwd.forward_scenes(
-                [self.planes * self.latents[s][None, :, None, None] for s in scene_ids], batch.positions)
+            from .fused_decoder import split_attrs
+            attrs = split_attrs(self.decoder_fwd.forward_scenes(
+                [self.planes * self.latents[s][None, :, None, None] for s in scene_ids], batch.positions))
         for b in range(B):
             gs = self.gaussians
             if attrs is not None:
-                a = attrs[b]
-                gs._xyz, gs._scaling, gs._rotation = a[:, 11:14], a[:, 8:11], a[:, 4:8]
-                gs._opacity, gs._features_dc = a[:, 3:4], a[:, 0:3].unsqueeze(1)
+                gs._xyz, gs._scaling, gs._rotation, gs._opacity, color = attrs[b]
+                gs._features_dc = color.unsqueeze(1)
             else:
                 planes = self.planes * self.latents[scene_ids[b]][None, :, None, None]
                 out = self.decoder_fwd(planes, batch.positions[b])
                 gs._xyz, gs._scaling, gs._rotation = out.xyz, out.scale, out.rotation
                 gs._opacity, gs._features_dc = out.opacity, out.color.unsqueeze(1)
             fov = float(batch.fov_deg[b]) / 360 * 2 * math.pi
-            cam = CustomCam(size=self.image_size, fov=fov, extr=batch.cam2world[b])
+            # the 4x4 algebra of the camera prologue on the host (a device-side inverse is a solver call with a host
+            # sync and ~40 tiny launches per scene), the three matrices uploaded once
+            cam = CustomCam(size=self.image_size, fov=fov, extr=batch.cam2world[b].cpu())
+            for name in ("world_view_transform", "full_proj_transform", "camera_center"):
+                setattr(cam, name, getattr(cam, name).to(self.device, non_blocking=True))
             image = self.render_fn(cam, gs, bg_color=self.bg, **self.render_kwargs)["render"][:3]
             target = batch.target[b]
             loss = (fused_image_loss if self.fused_loss else image_loss_torch)(image, target, **self.loss_w)[0]
