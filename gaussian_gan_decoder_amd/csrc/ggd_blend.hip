@@ -299,28 +299,31 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
 // every state update an exact no-op (T/(1-0) = T; the pending (last_alpha, last_color) pair is folded into the
 // running colour one record early and then applied with weight 0), so no per-pixel branches or selects on the
 // 8 words of recurrence state are needed.  1/(1-alpha) is one v_rcp + one Newton step, shared by both divisions.
-template <int EXP_MODE, bool CULL>
+template <int EXP_MODE, bool CULL, int PXL>
 __global__ __launch_bounds__(64) void blend_backward_kernel(
-    int W, int H, int gx, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ list,
+    int W, int H, int gx, int T_tiles, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ list,
     const uint32_t* __restrict__ ranges, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
   __shared__ float4 s_rec[64 * 3];
   __shared__ float s_sum[64 * 9];  // [record slot][component], written by lane 63 only
   const int lane = threadIdx.x;
-  const TileGeom g = tile_geom(gx, ranges);
+  constexpr int NP = PXL / 2;  // pixel pairs per lane
+  const WaveGeom<PXL> g(gx, T_tiles, ranges);
   const bool row_in = g.py < H;
   const size_t HW = (size_t)H * W;
   const size_t pix0 = (size_t)g.py * W + g.px0;
 
-  // per-pixel state, packed as pairs: [0] = pixels (0,1), [1] = pixels (2,3)
-  f2 T[2], nTfin[2], la[2], bgdot[2], acc[2][3], lastc[2][3], gpx[2][3];
-  const f2 px[2] = {{(float)g.px0, (float)(g.px0 + 1)}, {(float)(g.px0 + 2), (float)(g.px0 + 3)}};
-  uint32_t lastn[4];
+  // per-pixel state, packed as pairs: [p] = pixels (2p, 2p+1) of the lane
+  f2 T[NP], nTfin[NP], la[NP], bgdot[NP], acc[NP][3], lastc[NP][3], gpx[NP][3];
+  f2 px[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) px[p] = (f2){(float)(g.px0 + 2 * p), (float)(g.px0 + 2 * p + 1)};
+  uint32_t lastn[PXL];
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const float pyf = (float)g.py;
   uint32_t maxn = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < PXL; ++k) {
     const bool in = row_in && (g.px0 + k) < W;
     const float tf = in ? final_T[pix0 + k] : 0.0f;
     lastn[k] = in ? n_contrib[pix0 + k] : 0u;
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
     }
   }
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < NP; ++p) {
     la[p] = (f2){0.0f, 0.0f};
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) { acc[p][ch] = (f2){0.0f, 0.0f}; lastc[p][ch] = (f2){0.0f, 0.0f}; }
@@ -349,7 +352,8 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
   for (int d = 32; d >= 1; d >>= 1) maxn = max(maxn, (uint32_t)__shfl_xor((int)maxn, d, 64));
   if (maxn == 0) return;
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-  const float twx0 = (float)(g.px0 - (lane & 3) * 4), twy0 = (float)(g.py - (lane >> 2));  // the tile's pixel rectangle
+  constexpr int LPR = 16 / PXL, ROWS = 64 / LPR;
+  const float twx0 = (float)(g.px0 - (lane % LPR) * PXL), twy0 = (float)(g.py - lane / LPR);  // the wave's pixel rectangle
 
   uint32_t cend = g.lo + maxn;  // one past the last position that matters
   while (cend > g.lo) {
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
       q2.y = CULL ? L - (2e-5f + 1e-6f * fabsf(L)) : -__builtin_huge_valf();
       q2.z = __uint_as_float(my_id);
       q2.w = __uint_as_float((cstart - g.lo) + (uint32_t)lane);
-      keep = CULL ? record_box_hits(q0.x, q0.y, q0.z, q0.w, q1.x, q2.y, twx0, twx0 + 15.0f, twy0, twy0 + 15.0f) : true;
+      keep = CULL ? record_box_hits(q0.x, q0.y, q0.z, q0.w, q1.x, q2.y, twx0, twx0 + 15.0f, twy0, twy0 + (float)(ROWS - 1)) : true;
     }
     const uint64_t kept = __ballot(keep);
     const int nk = __popcll(kept);
@@ -387,21 +391,23 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
       const float dy = a.y - pyf;
       const float hA = -0.5f * a.z, nBdy = (-a.w) * dy, hCdy2 = ((-0.5f * b.x) * dy) * dy;
       const f2 gxx = {a.x, a.x};
-      f2 dx[2], pw[2];
+      f2 dx[NP], pw[NP];
+      bool need[PXL];
+      bool lane_need = false;
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
+      for (int p = 0; p < NP; ++p) {
         dx[p] = gxx - px[p];
         pw[p] = gauss_power2(hA, nBdy, hCdy2, dx[p]);
+        need[2 * p] = (pos0 < lastn[2 * p]) && (pw[p].x >= c2.y);
+        need[2 * p + 1] = (pos0 < lastn[2 * p + 1]) && (pw[p].y >= c2.y);
+        lane_need = lane_need || need[2 * p] || need[2 * p + 1];
       }
-      const bool n0 = (pos0 < lastn[0]) && (pw[0].x >= c2.y), n1 = (pos0 < lastn[1]) && (pw[0].y >= c2.y),
-                 n2 = (pos0 < lastn[2]) && (pw[1].x >= c2.y), n3 = (pos0 < lastn[3]) && (pw[1].y >= c2.y);
-      if (__ballot(n0 || n1 || n2 || n3) == 0ull) continue;  // nobody in the tile saw this Gaussian
-      const bool need[4] = {n0, n1, n2, n3};
+      if (__ballot(lane_need) == 0ull) continue;  // nobody in the wave saw this Gaussian
       f2 sc[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, sop = {0.f, 0.f}, scA = {0.f, 0.f}, scB = {0.f, 0.f},
          scC = {0.f, 0.f}, smx = {0.f, 0.f}, smy = {0.f, 0.f};
       bool any = false;
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
+      for (int p = 0; p < NP; ++p) {
         // exact per-pixel visibility test, then alpha = G = 0 for pixels that do not see the record
         f2 G, alpha;
         {
@@ -510,6 +516,9 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
   return GGD_OK;
 }
 
+// auto: below this many tiles the backward runs two waves per tile (measured: see DESIGN.md)
+constexpr int GGD_BWD_SPLIT_MAX_TILES = 4096;
+
 int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
                               const uint32_t* list, const uint32_t* ranges, const float* final_T,
                               const uint32_t* n_contrib, const float* dL_dpix, float* grad_acc) {
@@ -517,9 +526,19 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
   if (gx * gy == 0) return GGD_OK;
   const int em = ctx->opt[GGD_OPT_EXP_MODE];
   const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
-#define GGD_LAUNCH_BWD(EM, CU)                                                                                    \
-  hipLaunchKernelGGL((blend_backward_kernel<EM, CU>), dim3(gx * gy), dim3(64), 0, s, prm.width, prm.height, gx,  \
-                     splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc)
+  // two waves per tile (16x8 halves) when there are too few tiles to give every SIMD a couple of waves
+  const int T = gx * gy;
+  const int split = ctx->opt[GGD_OPT_BLEND_SPLIT];
+  const bool two = split == 2 || (split == 1 && T < GGD_BWD_SPLIT_MAX_TILES);
+#define GGD_LAUNCH_BWD(EM, CU)                                                                                          \
+  do {                                                                                                                  \
+    if (two)                                                                                                            \
+      hipLaunchKernelGGL((blend_backward_kernel<EM, CU, 2>), dim3(2 * T), dim3(64), 0, s, prm.width, prm.height, gx, T, \
+                         splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc);                           \
+    else                                                                                                                \
+      hipLaunchKernelGGL((blend_backward_kernel<EM, CU, 4>), dim3(T), dim3(64), 0, s, prm.width, prm.height, gx, T,     \
+                         splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc);                           \
+  } while (0)
   if (cull) {
     if (em == 0) GGD_LAUNCH_BWD(0, true); else if (em == 1) GGD_LAUNCH_BWD(1, true); else GGD_LAUNCH_BWD(2, true);
   } else {

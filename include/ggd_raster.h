@@ -196,8 +196,10 @@ enum {
                                  to 64 x 64 tiles, falls back to 2 beyond),
                              1 (default) = auto: 3 when num_rendered >= 3*2^18 (2 on larger grids, from 2^20), else 0.
                              debug=1 (key taps) or a tile grid beyond the LDS budget always uses 0 */
-  GGD_OPT_BLEND_SPLIT = 3, /* forward blend: 0 = one wave per 16x16 tile (4 px/lane), 2 = two waves per tile (16x8
-                             halves, 2 px/lane), 1 (default) = auto */
+  GGD_OPT_BLEND_SPLIT = 3, /* blend kernels: 0 = one wave per 16x16 tile (4 px/lane), 2 = two waves per tile (16x8
+                             halves, 2 px/lane), 1 (default) = auto (forward: two; backward: two below 4096 tiles,
+                             where one wave per tile cannot fill the 1024 SIMDs).  Forward results are identical; backward
+                             sums differ only in their fp32 summation order. */
   GGD_OPT_COUNT
 };
 int ggd_set_option(ggd_ctx* ctx, int option, int value);
