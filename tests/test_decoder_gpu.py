@@ -8,7 +8,8 @@ from gaussian_gan_decoder_amd.decoder import SequentialDecoderReverse, sample_fr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("C,H,W,N", [(32, 64, 64, 10000), (32, 256, 256, 200001), (8, 16, 24, 777), (64, 32, 32, 4096)])
+@pytest.mark.parametrize("C,H,W,N", [(32, 64, 64, 10000), (32, 256, 256, 200001), (8, 16, 24, 777), (64, 32, 32, 4096),
+                                     (32, 64, 48, 30011), (16, 40, 40, 20000)])   # the last three sizes with C in {16, 32} take the binned backward
 def test_triplane_mean_matches_torch(native_lib, C, H, W, N):
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(C + N)
