@@ -39,6 +39,31 @@ def scene_inputs(P, size, kind="cube", seed=0, sh_degree=0, use_colors=False, us
     return d
 
 
+def adversarial_inputs():
+    """Hand-made collisions and degenerate members: exact duplicates (equal depth bits -> order
+    by index), points behind / on the near plane, zero and full opacity, splats far larger than the image and smaller
+    than a pixel, off-screen centres, a zero quaternion, an oblique camera."""
+    d = scene_inputs(P=600, size=96, lsm=-4.0, seed=5, width=96, height=80, h=1.1, v=1.9)
+    g = torch.Generator().manual_seed(99)
+    xyz, op = d["means3D"].clone(), d["opacities"].clone()
+    sc, rot = d["scales"].clone(), d["rotations"].clone()
+    view = d["viewmatrix"]                      # row-vector convention: p_view = [p, 1] @ view
+    cam_pos = torch.inverse(view)[3, :3]
+    fwd = view[:3, 2]                           # world direction of +z_view
+    xyz[0:40] = xyz[40:80]; sc[0:40] = sc[40:80]; rot[0:40] = rot[40:80]; op[0:40] = op[40:80]   # exact duplicates
+    xyz[80:90] = cam_pos - 0.5 * fwd + 0.05 * torch.randn(10, 3, generator=g)        # behind the camera
+    xyz[90] = cam_pos + 0.2 * fwd                                                    # z_view ~ 0.2 (near-plane test)
+    xyz[91] = cam_pos + 0.2000001 * fwd
+    op[100:110] = 0.0; op[110:120] = 1.0; op[120:125] = 1.0 / 255.0
+    sc[130:136] = 3.0                                                                # covers the whole image many times
+    sc[140:150] = 1e-7                                                               # only the 0.3 low-pass remains
+    xyz[150:160] = xyz[150:160] + torch.tensor([5.0, 0.0, 0.0])                      # far off-screen
+    rot[160] = 0.0                                                                   # zero quaternion (degenerate R)
+    sc[170:175, 0] = 2.0; sc[170:175, 1:] = 1e-4                                     # needles
+    d.update(means3D=xyz.contiguous(), opacities=op.contiguous(), scales=sc.contiguous(), rotations=rot.contiguous())
+    return d
+
+
 def run_oracle(d, dtype=np.float32, stop_after=None):
     from oracle import ggd_oracle as O
     np_ = lambda t: None if t is None else t.numpy()

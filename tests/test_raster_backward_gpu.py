@@ -42,10 +42,11 @@ def _ids(c):
     return "-".join(f"{k}{v}" for k, v in c.items())
 
 
-@pytest.mark.parametrize("case", CASES, ids=_ids)
+@pytest.mark.parametrize("case", CASES + ["adversarial"], ids=lambda c: c if isinstance(c, str) else _ids(c))
 def test_backward_matches_oracle(native_lib, case):
     from oracle import ggd_oracle as O
-    d = scene_inputs(**case)
+    from _util import adversarial_inputs
+    d = adversarial_inputs() if case == "adversarial" else scene_inputs(**case)
     g = make_dL_dpix(max(d["W"], d["H"]))[:, :d["H"], :d["W"]].contiguous()
     o = run_oracle(d)
     n = run_native(d, debug=False)
@@ -53,6 +54,10 @@ def test_backward_matches_oracle(native_lib, case):
         pytest.skip("forward took a different threshold branch on some pixel (expf ulp); covered by forward test")
     ob = O.backward(o, g.numpy())
     nb = run_native_backward(d, n, g)
+    # the adversarial scene holds needles / image-sized splats whose derived gradients are ill-conditioned in fp32: there
+    # the fp32 oracle itself is far from its fp64 twin.  Members where it is are judged against the fp64 twin instead
+    # (the HIP result must not be further from it than 10x the fp32 oracle's own error).
+    ob64 = O.backward(run_oracle(d, dtype=np.float64), g.numpy().astype(np.float64)) if case == "adversarial" else None
     report = []
     worst = 0.0
     for name, ref in ob.items():
@@ -66,7 +71,16 @@ def test_backward_matches_oracle(native_lib, case):
         diff = np.abs(got.astype(np.float64) - ref.astype(np.float64))
         scale = max(1.0, float(np.abs(ref).max()))
         stol = STOL_DERIVED if name in DERIVED else STOL
-        ratio = diff / (ATOL + RTOL * np.abs(ref) + stol * scale)
+        tol = ATOL + RTOL * np.abs(ref) + stol * scale
+        ratio = diff / tol
+        if ob64 is not None:
+            ref64 = ob64[name].reshape(ref.shape)
+            own = np.abs(ref.astype(np.float64) - ref64)               # error of the fp32 oracle itself
+            rows = own.reshape(own.shape[0], -1)
+            ill = (rows > tol.reshape(rows.shape)).any(1)              # per Gaussian: any component ill-conditioned
+            own_row = np.broadcast_to(rows.max(1).reshape((-1,) + (1,) * (own.ndim - 1)), own.shape)
+            ill_b = np.broadcast_to(ill.reshape((-1,) + (1,) * (own.ndim - 1)), own.shape)
+            ratio = np.where(ill_b, np.abs(got.astype(np.float64) - ref64) / (10.0 * own_row + tol), ratio)
         report.append((name, float(diff.max()), scale, float(ratio.max())))
         assert np.isfinite(got).all(), name
         worst = max(worst, float(ratio.max()))

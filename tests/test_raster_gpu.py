@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import scene_inputs, run_oracle, run_native
+from _util import scene_inputs, run_oracle, run_native, adversarial_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -155,3 +155,19 @@ def test_blend_options_do_not_change_the_image(native_lib):
     finally:
         for o, v in zip((_capi.OPT_EXP_MODE, _capi.OPT_BLEND_CULL, _capi.OPT_BLEND_SPLIT), saved):
             cx.set_option(o, v)
+
+
+def test_collisions_and_degenerate_members(native_lib):
+    d = adversarial_inputs()
+    o = run_oracle(d)
+    assert (o["radii"] == 0).sum() >= 20 and o["tiles_touched"].max() == 6 * 5      # culled members, full-grid members
+    for path, dbg in ((0, True), (2, False), (3, False)):
+        n = run_native(d, debug=dbg, binning=path)
+        np.testing.assert_array_equal(n["radii"].cpu().numpy(), o["radii"])
+        np.testing.assert_array_equal(n["tiles_touched"], o["tiles_touched"])
+        assert n["num_rendered"] == o["num_rendered"]
+        np.testing.assert_array_equal(n["point_list"], o["point_list"])
+        np.testing.assert_array_equal(n["ranges"], o["ranges"])
+        same = n["n_contrib"] == o["n_contrib"]
+        assert (~same).sum() <= 1
+        assert np.abs(n["color"].cpu().numpy() - o["color"])[:, same].max() <= RGB_ATOL
