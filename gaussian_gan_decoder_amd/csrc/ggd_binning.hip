@@ -225,10 +225,13 @@ __device__ __forceinline__ void rs_store(uint32_t* p, uint32_t v) {
 // ghist[pass * 256 + digit] += occurrences, for every pass at once.  High key bytes are heavily skewed (tile bits of
 // consecutive instances, exponent byte of the depth): when a whole wave shares the digit one lane adds the count
 // instead of 64 conflicting LDS atomics.
-template <typename KeyT, int ITEMS>
+// SKIP (depth sort): keys equal to ~0 (culled Gaussians) are not counted; *n_valid += number of counted keys.
+template <typename KeyT, int ITEMS, bool SKIP = false>
 __global__ __launch_bounds__(RS_THREADS) void sort_global_hist_kernel(const KeyT* __restrict__ keys, int64_t n,
-                                                                      int passes, uint32_t* __restrict__ ghist) {
+                                                                      int passes, uint32_t* __restrict__ ghist,
+                                                                      uint32_t* __restrict__ n_valid = nullptr) {
   __shared__ uint32_t s_hist[RS_MAX_PASSES * RS_BINS];
+  uint32_t my_valid = 0;
   for (int b = threadIdx.x; b < passes * RS_BINS; b += RS_THREADS) s_hist[b] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * (RS_THREADS * ITEMS);
@@ -236,10 +239,11 @@ __global__ __launch_bounds__(RS_THREADS) void sort_global_hist_kernel(const KeyT
 #pragma unroll 4
   for (int k = 0; k < ITEMS; ++k) {
     const int64_t idx = base + (int64_t)k * RS_THREADS + threadIdx.x;
-    const bool ok = idx < n;
-    const KeyT key = ok ? keys[idx] : (KeyT)0;
+    const KeyT key = idx < n ? keys[idx] : (KeyT)0;
+    const bool ok = idx < n && !(SKIP && key == (KeyT)~(KeyT)0);
     const uint64_t act = __ballot(ok);
     if (act == 0ull) continue;
+    if (SKIP && (threadIdx.x & 63) == 0) my_valid += (uint32_t)__popcll(act);
     const int leader = __builtin_ctzll(act);
     for (int p = 0; p < passes; ++p) {
       const uint32_t d = (uint32_t)(key >> (8 * p)) & 0xffu;
@@ -256,13 +260,19 @@ __global__ __launch_bounds__(RS_THREADS) void sort_global_hist_kernel(const KeyT
     const uint32_t c = s_hist[b];
     if (c) atomicAdd(&ghist[b], c);
   }
+  if (SKIP && n_valid && my_valid) atomicAdd(n_valid, my_valid);
 }
 
-template <typename KeyT, bool IOTA, int ITEMS>
+// COMPACT (depth sort): pass 0 (IOTA) drops keys equal to ~0 -- they are neither ranked nor written -- and every later
+// pass takes its element count from *n_dev (= number of kept keys, written by the histogram kernel).  A later pass
+// whose digit is the same for all elements (ghist[d] == n: e.g. the exponent byte of a scene's depth range) degrades to
+// a tile copy: no ranking, no look-back.
+template <typename KeyT, bool IOTA, int ITEMS, bool COMPACT = false>
 __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
     const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, int64_t n, int shift, const uint32_t* __restrict__ ghist /*[256] of this pass*/,
-    uint32_t* status /*[ntiles][256]*/, uint32_t* ticket) {
+    uint32_t* __restrict__ vals_out, int64_t n_host, int shift, const uint32_t* __restrict__ ghist /*[256] of this pass*/,
+    uint32_t* status /*[ntiles][256]*/, uint32_t* ticket, const uint32_t* __restrict__ n_dev = nullptr) {
+  const int64_t n = (COMPACT && !IOTA) ? (int64_t)*n_dev : n_host;
   __shared__ uint32_t s_cnt[4][RS_BINS];   // per-wave running digit counts -> per-wave scatter bases
   __shared__ uint32_t s_scan[4];
   __shared__ uint32_t s_tile;
@@ -271,6 +281,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
   for (int b = threadIdx.x; b < 4 * RS_BINS; b += RS_THREADS) (&s_cnt[0][0])[b] = 0;
   __syncthreads();
   const uint32_t tile = s_tile;
+  if (COMPACT && (int64_t)tile * (RS_THREADS * ITEMS) >= n) return;   // beyond the kept elements (uniform per block)
 
   const int64_t wbase = (int64_t)tile * (RS_THREADS * ITEMS) + (int64_t)wv * (64 * ITEMS);
   KeyT key[ITEMS];
@@ -283,11 +294,23 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
     key[r] = ok ? keys_in[idx] : (KeyT)~(KeyT)0;
     val[r] = IOTA ? (uint32_t)idx : (ok ? vals_in[idx] : 0u);
   }
+  if (COMPACT && !IOTA) {
+    // constant digit: the pass is the identity permutation
+    const uint32_t d0 = (uint32_t)(keys_in[0] >> shift) & 0xffu;
+    if ((int64_t)ghist[d0] == n) {
+#pragma unroll
+      for (int r = 0; r < ITEMS; ++r) {
+        const int64_t idx = wbase + r * 64 + lane;
+        if (idx < n) { keys_out[idx] = key[r]; vals_out[idx] = val[r]; }
+      }
+      return;
+    }
+  }
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const int64_t idx = wbase + r * 64 + lane;
-    const bool ok = idx < n;
+    const bool ok = idx < n && !(COMPACT && IOTA && key[r] == (KeyT)~(KeyT)0);
     const uint32_t d = (uint32_t)(key[r] >> shift) & 0xffu;
     uint64_t peers = __ballot(ok);
 #pragma unroll
@@ -346,7 +369,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const int64_t idx = wbase + r * 64 + lane;
-    if (idx < n) {
+    if (idx < n && !(COMPACT && IOTA && key[r] == (KeyT)~(KeyT)0)) {
       const uint32_t d = (uint32_t)(key[r] >> shift) & 0xffu;
       const size_t dst = (size_t)s_cnt[wv][d] + rank[r];
       keys_out[dst] = key[r];
@@ -438,6 +461,10 @@ static int launch_sort_t(ggd_ctx* ctx, hipStream_t s, KeyT* keys_a, uint32_t* va
   return GGD_OK;
 }
 
+const uint32_t* ggd_sort32_nvalid_ptr(const void* tmp) {
+  return static_cast<const uint32_t*>(tmp) + RS_MAX_PASSES * RS_BINS + RS_MAX_PASSES;
+}
+
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes) {
   if (n <= 0) return GGD_OK;
@@ -450,8 +477,11 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
   uint32_t* status = reinterpret_cast<uint32_t*>(static_cast<char*>(tmp) + sort_ctrl_bytes());
   const size_t status_bytes = (size_t)passes * ntiles * RS_BINS * sizeof(uint32_t);
   GGD_HIP(hipMemsetAsync(tmp, 0, sort_ctrl_bytes() + status_bytes, s));
-  hipLaunchKernelGGL((sort_global_hist_kernel<uint32_t, RS32_ITEMS>), dim3(ntiles), dim3(RS_THREADS), 0, s, keys_src,
-                     n, passes, ghist);
+  // keys equal to 0xFFFFFFFF (culled Gaussians) are dropped by pass 0; n_valid (device) = number of kept keys, the
+  // element count of every later pass and of the binning that consumes the order (word RS_MAX_PASSES of the tickets)
+  uint32_t* n_valid = tickets + RS_MAX_PASSES;
+  hipLaunchKernelGGL((sort_global_hist_kernel<uint32_t, RS32_ITEMS, true>), dim3(ntiles), dim3(RS_THREADS), 0, s,
+                     keys_src, n, passes, ghist, n_valid);
   // pass 0: keys_src (read-only, caller's buffer) -> B with identity values; then B -> A -> B -> A ...
   const uint32_t* kin = keys_src;
   const uint32_t* vin = nullptr;
@@ -459,11 +489,12 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
     uint32_t* kout = (p & 1) ? keys_a : keys_b;
     uint32_t* vout = (p & 1) ? vals_a : vals_b;
     if (p == 0)
-      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, true, RS32_ITEMS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout,
-                         vout, n, 0, ghist, status, tickets);
+      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, true, RS32_ITEMS, true>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin,
+                         vin, kout, vout, n, 0, ghist, status, tickets, n_valid);
     else
-      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout,
-                         vout, n, 8 * p, ghist + p * RS_BINS, status + (size_t)p * ntiles * RS_BINS, tickets + p);
+      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin,
+                         vin, kout, vout, n, 8 * p, ghist + p * RS_BINS, status + (size_t)p * ntiles * RS_BINS, tickets + p,
+                         n_valid);
     kin = kout; vin = vout;
   }
   GGD_HIP(hipGetLastError());

@@ -343,10 +343,10 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
     }
     {
       StageTimer t(ctx, ST_DUPLICATE, s);
-      // culled Gaussians carry the key 0xFFFFFFFF: their count is bin 255 of the top-digit histogram of the depth sort
-      const uint32_t* culled = static_cast<const uint32_t*>(tmp) + 3 * 256 + 255;
-      rc = rowbin ? ggd_launch_rowbin(ctx, s, *prm, splat, va, culled, list, ranges, capacity, bin_tmp_ptr, bin_tmp)
-                  : ggd_launch_tilebin(ctx, s, *prm, splat, tiles, va, culled, list, ranges, capacity, bin_tmp_ptr, bin_tmp);
+      // the depth sort dropped the culled Gaussians (key 0xFFFFFFFF) and left the number of kept ones on the device
+      const uint32_t* n_vis = ggd_sort32_nvalid_ptr(tmp);
+      rc = rowbin ? ggd_launch_rowbin(ctx, s, *prm, splat, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp)
+                  : ggd_launch_tilebin(ctx, s, *prm, splat, tiles, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp);
       if (rc != GGD_OK) return rc;
     }
   } else {

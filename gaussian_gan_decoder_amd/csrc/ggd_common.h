@@ -75,6 +75,7 @@ int ggd_launch_duplicate(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, con
                          const uint32_t* tiles_touched, const uint32_t* offsets, uint64_t* keys, uint32_t* vals);
 size_t ggd_sort_tmp_bytes(int64_t n);
 size_t ggd_sort32_tmp_bytes(int64_t n);
+const uint32_t* ggd_sort32_nvalid_ptr(const void* tmp);  // device word: keys kept by ggd_launch_sort32_iota
 // stable LSD radix sort of (key,val) pairs on key bits [0,nbits); result ends in (keys_a, vals_a); the input must
 // have been placed in the buffer ggd_sort_input_is_alt(nbits) says.
 int ggd_sort_input_is_alt(int nbits);
@@ -88,12 +89,12 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
 bool ggd_rowbin_supported(int W, int H);
 size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity);
 int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat, const uint32_t* order,
-                      const uint32_t* culled_count, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
+                      const uint32_t* n_vis_ptr, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
                       size_t tmp_bytes);
 bool ggd_tilebin_supported(int T);
 size_t ggd_tilebin_tmp_bytes(int P, int T);
 int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
-                       const uint32_t* tiles_touched, const uint32_t* order, const uint32_t* culled_count,
+                       const uint32_t* tiles_touched, const uint32_t* order, const uint32_t* n_vis_ptr,
                        uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp, size_t tmp_bytes);
 int ggd_launch_ranges(ggd_ctx* ctx, hipStream_t s, const uint64_t* keys, int64_t n, uint32_t* ranges, int T);
 int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,

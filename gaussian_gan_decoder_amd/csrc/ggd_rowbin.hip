@@ -50,10 +50,10 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
 // ---- level 1 count: rect of every depth-ordered Gaussian (kept, packed, for the scatter) + per-row counts of the chunk
 __global__ __launch_bounds__(RB_THREADS) void rb_count1_kernel(int W, int H, const ggd_splat* __restrict__ splat,
                                                                const uint32_t* __restrict__ order,
-                                                               const uint32_t* __restrict__ culled_count, int P,
+                                                               const uint32_t* __restrict__ n_vis_ptr, int P,
                                                                uint2* __restrict__ packed, uint32_t* __restrict__ counts1) {
   __shared__ int diff[65];
-  const uint32_t n_vis = (uint32_t)P - *culled_count;
+  const uint32_t n_vis = min((uint32_t)P, *n_vis_ptr);
   const uint32_t base = (uint32_t)blockIdx.x * RB_CHUNK;
   if (base >= n_vis) return;
   const int gx = (W + 15) / 16, gy = (H + 15) / 16;
@@ -81,11 +81,11 @@ __global__ __launch_bounds__(RB_THREADS) void rb_count1_kernel(int W, int H, con
 // ---- scan over chunks, one workgroup, lane = bin: counts[c][bin] -> exclusive prefix within the bin; totals per bin
 //      level 1: rows of one segment (all chunks);   level 2 is handled per row in rb_scan2_kernel.
 __global__ __launch_bounds__(1024) void rb_scan1_kernel(uint32_t* __restrict__ counts1,
-                                                        const uint32_t* __restrict__ culled_count, int P,
+                                                        const uint32_t* __restrict__ n_vis_ptr, int P,
                                                         uint32_t* __restrict__ tab) {
   __shared__ uint32_t part[16][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t n_vis = (uint32_t)P - *culled_count;
+  const uint32_t n_vis = min((uint32_t)P, *n_vis_ptr);
   const int nb = (int)((n_vis + RB_CHUNK - 1) / RB_CHUNK);
   const int per = (nb + 15) / 16;
   const int r0 = min(nb, wv * per), r1 = min(nb, r0 + per);
@@ -181,13 +181,13 @@ __device__ __forceinline__ void wave_emit(const uint32_t (&iv)[RB_IPL], const ui
 
 // ---- level 1 scatter: {id, x0 | x1 << 8} into the list of every row in [y0, y1)
 __global__ __launch_bounds__(RB_THREADS) void rb_scatter1_kernel(const uint2* __restrict__ packed,
-                                                                 const uint32_t* __restrict__ culled_count, int P,
+                                                                 const uint32_t* __restrict__ n_vis_ptr, int P,
                                                                  const uint32_t* __restrict__ prefix1,
                                                                  const uint32_t* __restrict__ tab,
                                                                  uint2* __restrict__ ent, uint32_t ent_cap) {
   __shared__ int diff[RB_WAVES][65];
   __shared__ uint32_t wcnt[RB_WAVES][64];
-  const uint32_t n_vis = (uint32_t)P - *culled_count;
+  const uint32_t n_vis = min((uint32_t)P, *n_vis_ptr);
   const uint32_t base = (uint32_t)blockIdx.x * RB_CHUNK;
   if (base >= n_vis) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -351,7 +351,7 @@ size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity) {
 
 // capacity: upper bound on num_rendered (the level-1 entry count is <= num_rendered); order = depth-sorted ids.
 int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat, const uint32_t* order,
-                      const uint32_t* culled_count, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
+                      const uint32_t* n_vis_ptr, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
                       size_t tmp_bytes) {
   if (!ggd_rowbin_supported(prm.width, prm.height)) return ggd_fail(ctx, GGD_E_INVALID, "tile grid too large for row binning");
   if (tmp_bytes < ggd_rowbin_tmp_bytes(prm.P, capacity)) return ggd_fail(ctx, GGD_E_INVALID, "rowbin tmp too small");
@@ -365,9 +365,9 @@ int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const 
   const int nb1 = rb_blocks1(prm.P);
   const uint32_t nb2 = rb_blocks2(capacity);
   hipLaunchKernelGGL(rb_count1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, prm.width, prm.height, splat, order,
-                     culled_count, prm.P, packed, counts1);
-  hipLaunchKernelGGL(rb_scan1_kernel, dim3(1), dim3(1024), 0, s, counts1, culled_count, prm.P, tab);
-  hipLaunchKernelGGL(rb_scatter1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, packed, culled_count, prm.P, counts1, tab,
+                     n_vis_ptr, prm.P, packed, counts1);
+  hipLaunchKernelGGL(rb_scan1_kernel, dim3(1), dim3(1024), 0, s, counts1, n_vis_ptr, prm.P, tab);
+  hipLaunchKernelGGL(rb_scatter1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, packed, n_vis_ptr, prm.P, counts1, tab,
                      ent, capacity);
   hipLaunchKernelGGL(rb_count2_kernel, dim3(nb2), dim3(RB_THREADS), 0, s, ent, capacity, tab, counts2);
   hipLaunchKernelGGL(rb_scan2_kernel, dim3(gy), dim3(1024), 0, s, counts2, tab, gx, gy, ranges);

@@ -144,12 +144,12 @@ __device__ __forceinline__ void tb_for_rounds(TbPool& sh, uint32_t wbeg, uint32_
 __global__ __launch_bounds__(TB_THREADS) void tilebin_count_kernel(int W, int H, const ggd_splat* __restrict__ splat,
                                                                    const uint32_t* __restrict__ tiles_touched,
                                                                    const uint32_t* __restrict__ order,
-                                                                   const uint32_t* __restrict__ culled_count, int P,
+                                                                   const uint32_t* __restrict__ n_vis_ptr, int P,
                                                                    uint32_t* __restrict__ counts /*[nb][T]*/, int T) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TbPool& sh = *reinterpret_cast<TbPool*>(smem);
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + sizeof(TbPool));
-  const uint32_t n_vis = (uint32_t)P - *culled_count;
+  const uint32_t n_vis = min((uint32_t)P, *n_vis_ptr);
   if ((uint32_t)blockIdx.x * TB_G >= n_vis) return;
   const int gx = (W + 15) / 16, gy = (H + 15) / 16;
   for (int t = threadIdx.x; t < T; t += TB_THREADS) hist[t] = 0;
@@ -168,12 +168,12 @@ __global__ __launch_bounds__(TB_THREADS) void tilebin_count_kernel(int W, int H,
 // Block = 64 tiles (lane = tile) x 16 waves over the block rows: exclusive prefix over blocks, in place; tile totals.
 constexpr int TS_WAVES = 16;
 __global__ __launch_bounds__(64 * TS_WAVES) void tilebin_scan_kernel(uint32_t* __restrict__ counts, int T,
-                                                                     const uint32_t* __restrict__ culled_count, int P,
+                                                                     const uint32_t* __restrict__ n_vis_ptr, int P,
                                                                      uint32_t* __restrict__ totals) {
   __shared__ uint32_t part[TS_WAVES][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
-  const uint32_t n_vis = (uint32_t)P - *culled_count;
+  const uint32_t n_vis = min((uint32_t)P, *n_vis_ptr);
   const int nb = (int)((n_vis + TB_G - 1) / TB_G);
   const int per = (nb + TS_WAVES - 1) / TS_WAVES;
   const int r0 = min(nb, wv * per), r1 = min(nb, r0 + per);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64 * TS_WAVES) void tilebin_scan_kernel(uint32_t* _
 
 __global__ __launch_bounds__(TB_THREADS) void tilebin_scatter_kernel(
     int W, int H, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ tiles_touched,
-    const uint32_t* __restrict__ order, const uint32_t* __restrict__ culled_count, int P,
+    const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_vis_ptr, int P,
     const uint32_t* __restrict__ prefix /*[nb][T]*/, const uint32_t* __restrict__ totals, int T, int tbits,
     uint32_t* __restrict__ list, uint32_t* __restrict__ ranges, uint32_t capacity) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(TB_THREADS) void tilebin_scatter_kernel(
   uint32_t* base = reinterpret_cast<uint32_t*>(smem + sizeof(TbPool));           // [T]
   uint16_t* cnt = reinterpret_cast<uint16_t*>(smem + sizeof(TbPool) + (size_t)T * 4);  // [4][T]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint32_t n_vis = (uint32_t)P - *culled_count;
+  const uint32_t n_vis = min((uint32_t)P, *n_vis_ptr);
   const bool active = (uint32_t)blockIdx.x * TB_G < n_vis;
   if (!active && blockIdx.x != 0) return;
   const int gx = (W + 15) / 16, gy = (H + 15) / 16;
@@ -296,7 +296,7 @@ size_t ggd_tilebin_tmp_bytes(int P, int T) {
 }
 
 int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
-                       const uint32_t* tiles_touched, const uint32_t* order, const uint32_t* culled_count,
+                       const uint32_t* tiles_touched, const uint32_t* order, const uint32_t* n_vis_ptr,
                        uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp, size_t tmp_bytes) {
   const int T = ((prm.width + 15) / 16) * ((prm.height + 15) / 16);
   if (!ggd_tilebin_supported(T)) return ggd_fail(ctx, GGD_E_INVALID, "tile grid too large for the binning path");
@@ -317,10 +317,10 @@ int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const
     attr_set = true;
   }
   hipLaunchKernelGGL(tilebin_count_kernel, dim3(nb), dim3(TB_THREADS), lds_count, s, prm.width, prm.height, splat,
-                     tiles_touched, order, culled_count, prm.P, counts, T);
-  hipLaunchKernelGGL(tilebin_scan_kernel, dim3((T + 63) / 64), dim3(64 * TS_WAVES), 0, s, counts, T, culled_count, prm.P, totals);
+                     tiles_touched, order, n_vis_ptr, prm.P, counts, T);
+  hipLaunchKernelGGL(tilebin_scan_kernel, dim3((T + 63) / 64), dim3(64 * TS_WAVES), 0, s, counts, T, n_vis_ptr, prm.P, totals);
   hipLaunchKernelGGL(tilebin_scatter_kernel, dim3(nb), dim3(TB_THREADS), lds_scatter, s, prm.width, prm.height, splat,
-                     tiles_touched, order, culled_count, prm.P, counts, totals, T, tbits, list, ranges, capacity);
+                     tiles_touched, order, n_vis_ptr, prm.P, counts, totals, T, tbits, list, ranges, capacity);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }
