@@ -6,10 +6,13 @@
 //   * scan: two-level (per-block reduce -> one block scans the block sums -> per-block scan+offset);
 //   * duplicate: the 256 Gaussians of a block pool their instances and emit them with consecutive lanes writing
 //     consecutive instances (coalesced 8 B + 4 B stores) instead of one divergent per-Gaussian loop each;
-//   * sort: LSD radix, 8-bit digits over key bits [0, 32+msb(T)), stable by construction: per-block digit
-//     histograms -> exclusive scan in (digit, block) order -> per-block ranking with wave64 ballot matching
-//     (rank inside a wave = popcount of lower peer lanes), scatter.  Keys embed raw fp32 depth bits, so the
-//     sorted order (ties included) is identical to a stable sort of the emission order.
+//   * sort: onesweep LSD radix, 8-bit digits, stable by construction: ONE global histogram kernel for all passes, then
+//     one kernel per pass -- per-tile ranking with wave64 ballot matching (rank inside a wave = popcount of lower
+//     peer lanes), decoupled look-back over the earlier tiles' digit counts, scatter.  Two instantiations: 64-bit
+//     (tile | depth bits) keys over [0, 32+msb(T)) for the duplicateWithKeys path, and 32-bit depth keys with
+//     identity values for the tile-binning paths (ggd_tilebin.hip, ggd_rowbin.hip), where culled Gaussians are
+//     dropped in pass 0 and constant-digit passes degrade to copies.  Keys embed raw fp32 depth bits, so the sorted
+//     order (ties included) is identical to a stable sort of the emission order.
 #include "ggd_common.h"
 
 namespace {

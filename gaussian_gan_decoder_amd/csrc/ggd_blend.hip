@@ -4,17 +4,18 @@
 // gaussian_splatting/gaussian_renderer/__init__.py:167-175; algorithm restated in SURVEY.md 9.4 / 9.5).
 //
 // wave64 design (not the 16x16-thread block of the CUDA original):
-//   * ONE 64-lane wave owns one 16x16 tile; lane l owns the 4 horizontally adjacent pixels
-//     x = 16*tx + 4*(l&3) .. +3 of row y = 16*ty + (l>>2).  4 independent pixel chains per lane hide the
-//     exp / LDS latency, a row of the tile is written as 64 contiguous bytes, and the LDS cost of a record
-//     (3 x ds_read_b128 broadcast = 12 LDS cycles) is amortised over 4x the VALU work, which keeps the loop
-//     VALU-bound instead of LDS-bound.
-//   * The tile's sorted list is staged 64 records per round into LDS (lane j gathers record j: one 48 B
-//     ggd_splat, three 16 B loads), the next round's gather is issued before the current round is blended.
-//   * No workgroup barrier, no __syncthreads_count: "tile finished" is one wave-uniform ballot.
-//   * Backward: the 9 per-Gaussian partial gradients are first summed over the lane's 4 pixels, then over the
-//     wave with DPP row shifts (no LDS, no atomics), parked in LDS per staged record, and flushed with ONE
-//     global float atomic per (tile, Gaussian, component) instead of one per (pixel, Gaussian, component).
+//   * A 64-lane wave owns a 16x16 tile (4 horizontally adjacent pixels per lane) or a 16x8 half of it (2 pixels per
+//     lane; template PXL) -- two waves per tile give finer culling, earlier exits and more waves per SIMD.  The pixels
+//     of a lane are handled as packed pairs (v_pk_*_f32: two pixels per VALU issue), a tile row is written as
+//     contiguous bytes, and the LDS cost of a record (3 broadcast reads) is amortised over all the lane's pixels.
+//   * The tile's sorted list is consumed 64 records per round: lane j gathers record j (one 48 B ggd_splat, three
+//     16 B loads; the next round's gather is in flight while the current one is blended), tests the record's
+//     alpha >= 1/255 box against the wave's pixel rectangle, and only the survivors are staged, compacted, in LDS.
+//   * Per staged record: a wave-level cull in the power domain before any exp, then a branch-free packed update.
+//   * No workgroup barrier, no __syncthreads_count: "wave finished" is one wave-uniform ballot.
+//   * Backward: the 9 per-Gaussian partial gradients are first summed over the lane's pixels, then over the wave
+//     with DPP row shifts (no LDS, no atomics), parked in LDS per staged record, and flushed with ONE global float
+//     atomic per (wave, Gaussian, component) instead of one per (pixel, Gaussian, component).
 #include "ggd_common.h"
 
 namespace {
