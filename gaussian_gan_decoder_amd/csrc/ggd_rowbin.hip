@@ -132,6 +132,16 @@ __device__ __forceinline__ uint32_t wave_bin_counts(int* diff /*[65], zeroed*/, 
 // 64 x 64 bit-matrix transpose across the wave: lane i passes row i (bit b = M[i][b]) and gets column `lane`
 // (bit i = M[i][lane]).  Six butterfly stages (block sizes 32 .. 1): in every lane pair (l, l ^ d) the off-diagonal
 // d x d blocks are exchanged; one cross-lane move per 32-bit word and stage.
+template <int D, uint32_t M>
+__device__ __forceinline__ void tr_stage(uint32_t& lo, uint32_t& hi, uint32_t lane) {
+  const bool up = (lane & (uint32_t)D) != 0;
+  const uint32_t keep = up ? ~M : M;
+  const uint32_t slo = up ? ((lo & M) << D) : ((lo & ~M) >> D);
+  const uint32_t shi = up ? ((hi & M) << D) : ((hi & ~M) >> D);
+  lo = (lo & keep) | (uint32_t)__shfl_xor((int)slo, D, 64);
+  hi = (hi & keep) | (uint32_t)__shfl_xor((int)shi, D, 64);
+}
+
 __device__ __forceinline__ uint64_t wave_transpose64(uint64_t row) {
   const uint32_t lane = threadIdx.x & 63;
   uint32_t lo = (uint32_t)row, hi = (uint32_t)(row >> 32);
@@ -140,16 +150,12 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t row) {
     const uint32_t recv = (uint32_t)__shfl_xor((int)(up ? lo : hi), 32, 64);
     if (up) lo = recv; else hi = recv;
   }
-#pragma unroll
-  for (int d = 16; d >= 1; d >>= 1) {
-    const uint32_t m = d == 16 ? 0x0000FFFFu : d == 8 ? 0x00FF00FFu : d == 4 ? 0x0F0F0F0Fu : d == 2 ? 0x33333333u : 0x55555555u;
-    const bool up = (lane & (uint32_t)d) != 0;
-    const uint32_t keep = up ? ~m : m;
-    const uint32_t slo = up ? ((lo & m) << d) : ((lo & ~m) >> d);
-    const uint32_t shi = up ? ((hi & m) << d) : ((hi & ~m) >> d);
-    lo = (lo & keep) | (uint32_t)__shfl_xor((int)slo, d, 64);
-    hi = (hi & keep) | (uint32_t)__shfl_xor((int)shi, d, 64);
-  }
+  // stages 16 .. 1 act on the two 32-bit words independently (compile-time masks and lane distances)
+  tr_stage<16, 0x0000FFFFu>(lo, hi, lane);
+  tr_stage<8, 0x00FF00FFu>(lo, hi, lane);
+  tr_stage<4, 0x0F0F0F0Fu>(lo, hi, lane);
+  tr_stage<2, 0x33333333u>(lo, hi, lane);
+  tr_stage<1, 0x55555555u>(lo, hi, lane);
   return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
@@ -163,7 +169,7 @@ __device__ __forceinline__ void wave_emit(const uint32_t (&iv)[RB_IPL], const ui
                                           const uint32_t (&pb)[RB_IPL], int n_items, uint32_t& dst, Emit&& emit) {
 #pragma unroll
   for (int q = 0; q < RB_IPL; ++q) {
-    if (q * 64 >= n_items) break;
+    if (q * 64 >= n_items) continue;   // (no `break`: keeps the loop fully unrollable, iv / pa / pb stay in registers)
     const uint32_t l = iv[q] & 0xffu, h = iv[q] >> 8;
     const uint64_t below_h = h >= 64u ? ~0ull : ((1ull << h) - 1ull);
     const uint64_t row = h > l ? (below_h & ~((1ull << l) - 1ull)) : 0ull;
