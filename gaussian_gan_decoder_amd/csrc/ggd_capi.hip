@@ -243,7 +243,7 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
   rc = ggd_reserve_scratch(ctx, scan_tmp, s);
   if (rc != GGD_OK) return rc;
   if (prm->prefiltered) GGD_HIP(hipMemsetAsync(ctx->d_words + 1, 0, sizeof(uint32_t), s));
-  GGD_HIP(hipMemsetAsync(header, 0, 256, s));
+  (void)header;   // reserved words of the geometry buffer (not written by the current kernels)
   {
     StageTimer t(ctx, ST_PREPROCESS, s);
     rc = ggd_launch_preprocess(ctx, s, *prm, means3D, shs, colors_precomp, opacities, scales, rotations,
