@@ -87,6 +87,23 @@ def cpu_baseline(P, S, kind, budget_s=25.0):
             "host_cores": os.cpu_count()}
 
 
+def pmc_valu(workload, stage):
+    """SQ_INSTS_VALU per launch of the stage's kernel from the same committed PMC pass (see pmc_traffic)."""
+    import glob
+    best = None
+    for fn in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "traffic.json"))):
+        try:
+            doc = json.load(open(fn))
+        except (OSError, ValueError):
+            continue
+        if doc.get("workload") != workload:
+            continue
+        k = doc.get("kernels", {}).get(doc.get("stage_to_kernel", {}).get(stage, ""))
+        if k and "valu_wave_insts" in k:
+            best = k["valu_wave_insts"]
+    return best
+
+
 def pmc_traffic(workload, stage):
     """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     corrected as profiles/*/traffic.json states).  bench.py cannot collect counters itself; the number is the one
@@ -333,7 +350,11 @@ def main():
                    "tiles": ((S + 15) // 16) ** 2, "parallelism": f"scene-parallel x{world} (no collective)"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, dom),
-                     "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": stage_ms[dom]},
+                     "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": stage_ms[dom],
+                     # the dominant kernel is VALU-bound by intensity: also report its VALU issue fraction
+                     # (committed PMC instruction count x 4 cycles / (1024 SIMDs x live kernel time x 2.4 GHz))
+                     "valu_issue_frac": (lambda v: None if v is None else v * 4.0 / (1024 * dom_s * 2.4e9))(
+                         pmc_valu(args.workload, dom))},
         "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
         "whole_frame": {"algorithmic_bytes": whole, "GBps": whole / (ms_per_step * 1e-3) / 1e9,
                         "frac_of_hbm_peak": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
