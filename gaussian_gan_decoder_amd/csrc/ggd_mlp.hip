@@ -303,7 +303,7 @@ extern "C" int ggd_decoder_backward(ggd_ctx* ctx, void* stream, int32_t N, const
   int grid = (N + MLP_WAVES * SLAB - 1) / (MLP_WAVES * SLAB);
   if (grid > 256) grid = 256;
   hipLaunchKernelGGL(decoder_backward_kernel, dim3(grid), dim3(MLP_THREADS), HEADT_BYTES, static_cast<hipStream_t>(stream),
-                     N, static_cast<const unsigned char*>(packed_t), attrs, dattrs, static_cast<const __bf16*>(zbuf),
+                     N, 0, N, static_cast<const unsigned char*>(packed_t), attrs, dattrs, static_cast<const __bf16*>(zbuf),
                      static_cast<__bf16*>(dzbuf), dout, dfeat, dinfo);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
@@ -338,8 +338,49 @@ extern "C" int ggd_decoder_wgrad(ggd_ctx* ctx, void* stream, int32_t N, const vo
   if (chunks > 64) chunks = 64;
   if (chunks < 1) chunks = 1;
   hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(chunks, NHEAD * 4), dim3(WG_THREADS), WG_LDS,
-                     static_cast<hipStream_t>(stream), N, static_cast<const __bf16*>(zbuf),
+                     static_cast<hipStream_t>(stream), N, 0, N, static_cast<const __bf16*>(zbuf),
                      static_cast<const __bf16*>(dzbuf), dout, feat, pos, attrs, wgrad);
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
+// Backward + weight gradients in point CHUNKS: the backward kernel of a chunk is followed immediately by the weight-
+// gradient kernel of the same chunk, so that the dz / z rows it reads are still in the 256 MB Infinity Cache instead of
+// coming back from HBM.  chunk <= 0: one chunk (= ggd_decoder_backward followed by ggd_decoder_wgrad).
+extern "C" int ggd_decoder_backward_wgrad(ggd_ctx* ctx, void* stream, int32_t N, int32_t chunk, const void* packed_t,
+                                          const float* attrs, const float* dattrs, const void* zbuf, void* dzbuf,
+                                          float* dout, float* dfeat, float* dinfo, const float* feat, const float* pos,
+                                          float* wgrad) {
+  if (!ctx) return GGD_E_INVALID;
+  if (N < 0) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_backward_wgrad: N < 0");
+  if (N == 0) return GGD_OK;
+  if (!packed_t || !attrs || !dattrs || !zbuf || !dzbuf || !dout || !dfeat || !dinfo || !feat || !pos || !wgrad)
+    return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_backward_wgrad: NULL pointer");
+  static bool attr_set = false;
+  if (!attr_set) {
+    GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_backward_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEADT_BYTES));
+    GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_wgrad_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
+    attr_set = true;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (chunk <= 0 || chunk > N) chunk = N;
+  chunk = (chunk + 255) / 256 * 256;
+  for (int32_t first = 0; first < N; first += chunk) {
+    const int32_t last = first + chunk < N ? first + chunk : N;
+    const int32_t n = last - first;
+    int grid = (n + MLP_WAVES * SLAB - 1) / (MLP_WAVES * SLAB);
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL(decoder_backward_kernel, dim3(grid), dim3(MLP_THREADS), HEADT_BYTES, s, N, first, last,
+                       static_cast<const unsigned char*>(packed_t), attrs, dattrs, static_cast<const __bf16*>(zbuf),
+                       static_cast<__bf16*>(dzbuf), dout, dfeat, dinfo);
+    int chunks = (n + 4 * WG_K - 1) / (4 * WG_K);
+    if (chunks > 64) chunks = 64;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(chunks, NHEAD * 4), dim3(WG_THREADS), WG_LDS, s, N, first, last,
+                       static_cast<const __bf16*>(zbuf), static_cast<const __bf16*>(dzbuf), dout, feat, pos, attrs, wgrad);
+  }
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }

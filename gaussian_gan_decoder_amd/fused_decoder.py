@@ -107,6 +107,12 @@ def _splitk_dw(dy: torch.Tensor, x: torch.Tensor, chunk: int = 4096) -> torch.Te
     return dw
 
 
+import os as _os
+
+# points per backward / weight-gradient chunk (z + dz of a chunk = 15 KiB per point; 0 = no chunking)
+WGRAD_CHUNK = int(_os.environ.get("GGD_WGRAD_CHUNK", "0"))
+
+
 class FusedDecoderFn(torch.autograd.Function):
     """attrs[N,16] = fused 5-head decoder(feats[N,32], pos[N,3]; 40 weight/bias tensors), differentiable w.r.t. feats
     and the parameters.  Forward and activation-backward are the bf16-MFMA kernels; the weight gradients are split-K
@@ -141,19 +147,17 @@ class FusedDecoderFn(torch.autograd.Function):
         dout = torch.empty((5, n, 4), dtype=torch.float32, device=dev)
         dfeat = torch.empty((n, 32), dtype=torch.float32, device=dev)
         dinfo = torch.empty((n, 16), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            cx.check(cx.lib.ggd_decoder_backward(
-                cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), n, C.c_void_p(packed_t.data_ptr()),
-                C.c_void_p(attrs.data_ptr()), C.c_void_p(dattrs.data_ptr()), C.c_void_p(zbuf.data_ptr()),
-                C.c_void_p(dzbuf.data_ptr()), C.c_void_p(dout.data_ptr()), C.c_void_p(dfeat.data_ptr()),
-                C.c_void_p(dinfo.data_ptr())))
         per_head = cx.lib.ggd_decoder_wgrad_floats() // 5
         wg = torch.zeros((5, per_head), dtype=torch.float32, device=dev)
+        # activation backward + weight gradients, chunk by chunk (WGRAD_CHUNK points): a chunk's dz / z rows are consumed by
+        # the weight-gradient kernel while they are still in the Infinity Cache
         with torch.cuda.device(dev):
-            cx.check(cx.lib.ggd_decoder_wgrad(
-                cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), n, C.c_void_p(zbuf.data_ptr()),
-                C.c_void_p(dzbuf.data_ptr()), C.c_void_p(dout.data_ptr()), C.c_void_p(feats.data_ptr()),
-                C.c_void_p(pos.data_ptr()), C.c_void_p(attrs.data_ptr()), C.c_void_p(wg.data_ptr())))
+            cx.check(cx.lib.ggd_decoder_backward_wgrad(
+                cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), n, int(WGRAD_CHUNK),
+                C.c_void_p(packed_t.data_ptr()), C.c_void_p(attrs.data_ptr()), C.c_void_p(dattrs.data_ptr()),
+                C.c_void_p(zbuf.data_ptr()), C.c_void_p(dzbuf.data_ptr()), C.c_void_p(dout.data_ptr()),
+                C.c_void_p(dfeat.data_ptr()), C.c_void_p(dinfo.data_ptr()), C.c_void_p(feats.data_ptr()),
+                C.c_void_p(pos.data_ptr()), C.c_void_p(wg.data_ptr())))
         grads = []
         for h in range(5):
             in_dim, od = 35 + _N_EXTRA[h], _OUT_DIM[h]

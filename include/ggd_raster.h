@@ -280,6 +280,12 @@ size_t ggd_image_loss_tmp_bytes(int32_t W, int32_t H);
 int ggd_image_loss(ggd_ctx* ctx, void* stream, int32_t W, int32_t H, const float* image, const float* target,
                    const float* weights4, float* terms5, float* grad_image, void* tmp, size_t tmp_bytes);
 
+/* ggd_decoder_backward + ggd_decoder_wgrad over point chunks of `chunk` points (<= 0: one chunk), each chunk's weight-
+ * gradient kernel launched right behind its backward kernel so that it reads dz / z from the Infinity Cache. */
+int ggd_decoder_backward_wgrad(ggd_ctx* ctx, void* stream, int32_t N, int32_t chunk, const void* packed_t,
+                               const float* attrs, const float* dattrs, const void* zbuf, void* dzbuf, float* dout,
+                               float* dfeat, float* dinfo, const float* feat, const float* pos, float* wgrad);
+
 /* Per-stage device time (ms, hipEvent pairs on `stream`) of the most recent forward_geometry / forward_render /
  * backward call when profiling is on.  Stage names: ggd_stage_name(i), i in [0, ggd_stage_count()). */
 int ggd_set_profiling(ggd_ctx* ctx, int enabled);
