@@ -191,6 +191,14 @@ def main():
         elapsed = float(t.item())
     num_rendered = out[0]
 
+    # ---- per-frame device time distribution (hipEvent pairs on the launch stream; SURVEY 8d: median and p10 / p90)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(100, max(20, args.steps)))]
+    for a_, b_ in evs:
+        a_.record(); step(); b_.record()
+    torch.cuda.synchronize(dev)
+    fm = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
+    frame_pct = {"p10": fm[len(fm) // 10], "p50": fm[len(fm) // 2], "p90": fm[(len(fm) * 9) // 10], "n": len(fm)}
+
     # ---- per-stage device times (hipEvent pairs on the launch stream), measured live over a second timed region
     ctx = _capi.context_for(dev)
     ctx.set_profiling(True)
@@ -356,6 +364,7 @@ def main():
                      "valu_issue_frac": (lambda v: None if v is None else v * 4.0 / (1024 * dom_s * 2.4e9))(
                          pmc_valu(args.workload, dom))},
         "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+        "frame_ms_percentiles": {k: (round(v, 5) if k != "n" else v) for k, v in frame_pct.items()},
         "whole_frame": {"algorithmic_bytes": whole, "GBps": whole / (ms_per_step * 1e-3) / 1e9,
                         "frac_of_hbm_peak": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
