@@ -20,10 +20,14 @@ enum {
   ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT
 };
 
+enum { GGD_ATTR_MLP_FWD = 1, GGD_ATTR_MLP_BWD = 2, GGD_ATTR_MLP_WGRAD = 4, GGD_ATTR_TILEBIN = 8, GGD_ATTR_TRIPLANE32 = 16,
+       GGD_ATTR_TRIPLANE16 = 32 };
+
 struct ggd_ctx {
   int device = 0;
   void* scratch = nullptr;      // grow-only device workspace (sort histograms, scan block sums, dL_dconic, ...)
   size_t scratch_bytes = 0;
+  uint32_t attr_mask = 0;       // GGD_ATTR_* bits: kernels whose dynamic-LDS limit was raised on this ctx's device
   uint32_t* d_words = nullptr;  // small device control block: [0] total R, [1] prefilter trap flag
   uint32_t* h_words = nullptr;  // pinned host mirror
   void* dbg_keys = nullptr;     // debug copy of the unsorted list

@@ -254,13 +254,12 @@ static int decoder_forward_impl(ggd_ctx* ctx, void* stream, const float* feat, c
   if (N == 0) return GGD_OK;
   if (!feat || !pos || !packed_weights || !attrs) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_forward: NULL pointer");
   const size_t lds = HEAD_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(ctx->attr_mask & GGD_ATTR_MLP_FWD)) {
     GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_forward_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_forward_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    ctx->attr_mask |= GGD_ATTR_MLP_FWD;
   }
   int grid = (N + MLP_WAVES * SLAB - 1) / (MLP_WAVES * SLAB);  // at least one slab per wave
   if (grid > 256) grid = 256;
@@ -290,11 +289,10 @@ extern "C" int ggd_decoder_backward(ggd_ctx* ctx, void* stream, int32_t N, const
   if (N == 0) return GGD_OK;
   if (!packed_t || !attrs || !dattrs || !zbuf || !dzbuf || !dout || !dfeat || !dinfo)
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_backward: NULL pointer");
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(ctx->attr_mask & GGD_ATTR_MLP_BWD)) {
     GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_backward_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEADT_BYTES));
-    attr_set = true;
+    ctx->attr_mask |= GGD_ATTR_MLP_BWD;
   }
   int grid = (N + MLP_WAVES * SLAB - 1) / (MLP_WAVES * SLAB);
   if (grid > 256) grid = 256;
@@ -323,11 +321,10 @@ extern "C" int ggd_decoder_wgrad(ggd_ctx* ctx, void* stream, int32_t N, const vo
   if (N == 0) return GGD_OK;
   if (!zbuf || !dzbuf || !dout || !feat || !pos || !attrs || !wgrad)
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_wgrad: NULL pointer");
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(ctx->attr_mask & GGD_ATTR_MLP_WGRAD)) {
     GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_wgrad_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
-    attr_set = true;
+    ctx->attr_mask |= GGD_ATTR_MLP_WGRAD;
   }
   // split-K: ~4 workgroups per CU over the 20 (head, layer) problems; at least 4 stages per workgroup
   int chunks = (N + 4 * WG_K - 1) / (4 * WG_K);
@@ -352,13 +349,12 @@ extern "C" int ggd_decoder_backward_wgrad(ggd_ctx* ctx, void* stream, int32_t N,
   if (N == 0) return GGD_OK;
   if (!packed_t || !attrs || !dattrs || !zbuf || !dzbuf || !dout || !dfeat || !dinfo || !feat || !pos || !wgrad)
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_backward_wgrad: NULL pointer");
-  static bool attr_set = false;
-  if (!attr_set) {
+  if ((ctx->attr_mask & (GGD_ATTR_MLP_BWD | GGD_ATTR_MLP_WGRAD)) != (GGD_ATTR_MLP_BWD | GGD_ATTR_MLP_WGRAD)) {
     GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_backward_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEADT_BYTES));
     GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_wgrad_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
-    attr_set = true;
+    ctx->attr_mask |= GGD_ATTR_MLP_BWD | GGD_ATTR_MLP_WGRAD;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (chunk <= 0 || chunk > N) chunk = N;

@@ -308,13 +308,12 @@ int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const
   while ((1 << tbits) < T) ++tbits;
   const size_t lds_count = sizeof(TbPool) + (size_t)T * 4;
   const size_t lds_scatter = sizeof(TbPool) + (size_t)T * 4 + (size_t)T * 8;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(ctx->attr_mask & GGD_ATTR_TILEBIN)) {
     GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tilebin_count_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tilebin_scatter_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    attr_set = true;
+    ctx->attr_mask |= GGD_ATTR_TILEBIN;
   }
   hipLaunchKernelGGL(tilebin_count_kernel, dim3(nb), dim3(TB_THREADS), lds_count, s, prm.width, prm.height, splat,
                      tiles_touched, order, n_vis_ptr, prm.P, counts, T);

@@ -299,11 +299,11 @@ int launch_binned_backward(ggd_ctx* ctx, hipStream_t s, int H, int W, const floa
                      tab + 2 * tg.nbins + 2, items);
   const unsigned acc_blocks = (unsigned)(((3 * (size_t)N + TPB_CHUNK - 1) / TPB_CHUNK + tg.nbins + 3) / 4);
   const size_t tile_lds = (size_t)4 * (TPB_TS + 1) * (TPB_TS + 1) * C * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  constexpr uint32_t kBit = C == 32 ? GGD_ATTR_TRIPLANE32 : GGD_ATTR_TRIPLANE16;
+  if (!(ctx->attr_mask & kBit)) {
     GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tpb_accumulate_kernel<C>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
-    attr_set = true;
+    ctx->attr_mask |= kBit;
   }
   hipLaunchKernelGGL((tpb_accumulate_kernel<C>), dim3(acc_blocks), dim3(256), tile_lds, s, pos, items, tab, H, W, scale,
                      dout, dplanes_cl);
