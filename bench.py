@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backward", action="store_true", help="also time forward+backward (reported under 'extra')")
     ap.add_argument("--no-train", action="store_true", help="skip the data-parallel train-step section")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the forward-fps sweep over the other synthetic configs")
     ap.add_argument("--no-decode", action="store_true", help="skip the fused decode + render section (config 3)")
     ap.add_argument("--train-iters", type=int, default=8)
     ap.add_argument("--train-points", type=int, default=500_000, help="positions per scene (reference: 500 000)")
@@ -210,7 +211,35 @@ def main():
             acc[k] = acc.get(k, 0.0) + v
     stage_ms = {k: v / nprof for k, v in acc.items()}
     extra = {}
+    ctx.set_profiling(False)
+    if not args.no_sweep and rank == 0:
+        # the other synthetic configurations of BASELINE.json's north_star ({100k, 1M} x {512, 1024}), forward raster only,
+        # 100 frames each -- reported for the table in DESIGN.md; the headline `value` is the workload above
+        sweep = {}
+        for name in ("100k_512_cube", "100k_1024_cube", "1M_512_cube"):
+            if name == args.workload:
+                continue
+            P2, S2, kind2 = WORKLOADS[name]
+            sc2 = make_scene(P2, S2, kind2, seed=0).to(dev)
+            cam2 = sc2.cam
+            a2 = (sc2.bg, sc2.xyz, empty, sc2.opacities.contiguous(), sc2.scales.contiguous(), sc2.rotations.contiguous(), 1.0,
+                  empty, cam2.world_view_transform, cam2.full_proj_transform, math.tan(cam2.FoVx * 0.5),
+                  math.tan(cam2.FoVy * 0.5), S2, S2, sc2.features_dc.contiguous(), 0, cam2.camera_center, False, False)
+            for _ in range(10):
+                o2 = R.rasterize_gaussians_native(*a2)
+            torch.cuda.synchronize(dev)
+            batches = []
+            for _ in range(5):   # median of 5 batches of 20 frames (one allocator hiccup must not decide the number)
+                t2 = time.perf_counter()
+                for _ in range(20):
+                    o2 = R.rasterize_gaussians_native(*a2)
+                torch.cuda.synchronize(dev)
+                batches.append((time.perf_counter() - t2) / 20)
+            sweep[name] = {"frames_per_s": 1.0 / sorted(batches)[2], "num_rendered": int(o2[0])}
+            del sc2, a2, o2
+        extra["forward_fps_other_workloads"] = sweep
     if args.backward:
+        ctx.set_profiling(True)
         g = make_dL_dpix(S).to(dev)
         out = step()
         bargs = (sc.bg, sc.xyz, out[2], empty, scales, rots, 1.0, empty, cam.world_view_transform,
