@@ -455,11 +455,10 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
       }
       if (__ballot(any) != 0ull) {  // wave-uniform: somebody in the tile saw this Gaussian
         touched |= 1ull << j;
-        const float t0 = ggd_wave_sum_to63(sc[0].x + sc[0].y), t1 = ggd_wave_sum_to63(sc[1].x + sc[1].y),
-                    t2 = ggd_wave_sum_to63(sc[2].x + sc[2].y), t3 = ggd_wave_sum_to63(sop.x + sop.y),
-                    t4 = ggd_wave_sum_to63(scA.x + scA.y), t5 = ggd_wave_sum_to63(scB.x + scB.y),
-                    t6 = ggd_wave_sum_to63(scC.x + scC.y), t7 = ggd_wave_sum_to63(smx.x + smx.y),
-                    t8 = ggd_wave_sum_to63(smy.x + smy.y);
+        float t[9] = {sc[0].x + sc[0].y, sc[1].x + sc[1].y, sc[2].x + sc[2].y, sop.x + sop.y, scA.x + scA.y,
+                      scB.x + scB.y, scC.x + scC.y, smx.x + smx.y, smy.x + smy.y};
+        ggd_wave_sum9_to63(t);
+        const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5], t6 = t[6], t7 = t[7], t8 = t[8];
         if (lane == 63) {
           float* o = s_sum + j * 9;
           o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = t5; o[6] = t6; o[7] = t7; o[8] = t8;

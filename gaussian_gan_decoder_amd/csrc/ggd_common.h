@@ -133,6 +133,31 @@ __device__ __forceinline__ int ggd_tile_rect(float px, float py, int irad, int g
   return (maxx - minx) * (maxy - miny);
 }
 
+// Nine wave sums at once (the blend backward's per-Gaussian partials), totals valid in lane 63.  Same six DPP steps as
+// ggd_wave_sum_to63, written as v_add_f32_dpp so that each step is ONE instruction per value (through the builtin the
+// compiler emits v_mov_b32_dpp + a packed add: 1.5 per value).  The nine chains are interleaved step by step, which
+// also provides the wait states a DPP read of a freshly written VGPR needs (the hazard recogniser does not look inside
+// inline asm); the leading s_nop covers the producers of the inputs.
+#define GGD_DPP9(ctrl)                                                                                          \
+  asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\t"                      \
+               "v_add_f32_dpp %2, %2, %2 " ctrl "\n\tv_add_f32_dpp %3, %3, %3 " ctrl "\n\t"                      \
+               "v_add_f32_dpp %4, %4, %4 " ctrl "\n\tv_add_f32_dpp %5, %5, %5 " ctrl "\n\t"                      \
+               "v_add_f32_dpp %6, %6, %6 " ctrl "\n\tv_add_f32_dpp %7, %7, %7 " ctrl "\n\t"                      \
+               "v_add_f32_dpp %8, %8, %8 " ctrl                                                                 \
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), \
+                 "+v"(v[8]))
+__device__ __forceinline__ void ggd_wave_sum9_to63(float (&v)[9]) {
+  asm volatile("s_nop 1");
+  GGD_DPP9("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+  GGD_DPP9("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+  GGD_DPP9("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+  GGD_DPP9("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+  GGD_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf");
+  GGD_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf");
+  asm volatile("s_nop 1");
+}
+#undef GGD_DPP9
+
 // Sum over the 64 lanes of a wave with DPP row shifts / broadcasts; the total is valid in lane 63.
 // (Hillis-Steele inclusive scan inside each 16-lane row, then row_bcast:15 into rows 1/3 and row_bcast:31 into
 // rows 2/3; lanes without a valid source add the `old` operand = 0.)
