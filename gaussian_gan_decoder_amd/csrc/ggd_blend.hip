@@ -428,37 +428,41 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
           i1 = __builtin_fmaf(i1, __builtin_fmaf(-om.y, i1, 1.0f), i1);
           inv = (f2){i0, i1};
         }
+        // Explicit packed FMAs (the build runs with -ffp-contract=off); the per-record constants -- opacity,
+        // -1/2, the 0.5 W / 0.5 H of the pixel-to-NDC map and the minus sign of dG/d(delta) -- are applied once to the
+        // reduced sums below instead of to every pixel.
         T[p] = T[p] * inv;
         const f2 dchannel_dcolor = alpha * T[p];
         const f2 oml = 1.0f - la[p];
         f2 dL_dalpha = {0.0f, 0.0f};
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          acc[p][ch] = la[p] * lastc[p][ch] + oml * acc[p][ch];
+          acc[p][ch] = __builtin_elementwise_fma(la[p], lastc[p][ch], oml * acc[p][ch]);
           lastc[p][ch] = (f2){col[ch], col[ch]};
-          dL_dalpha += (col[ch] - acc[p][ch]) * gpx[p][ch];
-          sc[ch] += dchannel_dcolor * gpx[p][ch];
+          dL_dalpha = __builtin_elementwise_fma(col[ch] - acc[p][ch], gpx[p][ch], dL_dalpha);
+          sc[ch] = __builtin_elementwise_fma(dchannel_dcolor, gpx[p][ch], sc[ch]);
         }
-        dL_dalpha *= T[p];
         la[p] = alpha;
-        dL_dalpha += (nTfin[p] * inv) * bgdot[p];
-        const f2 dL_dG = b.y * dL_dalpha;
+        dL_dalpha = __builtin_elementwise_fma(nTfin[p] * inv, bgdot[p], dL_dalpha * T[p]);
         const f2 gdx = G * dx[p], gdy = G * dy;
-        const f2 dG_ddelx = -gdx * a.z - gdy * a.w;
-        const f2 dG_ddely = -gdy * b.x - gdx * a.w;
-        smx += dL_dG * dG_ddelx * ddelx_dx;
-        smy += dL_dG * dG_ddely * ddely_dy;
-        scA += -0.5f * gdx * dx[p] * dL_dG;
-        scB += -0.5f * gdx * dy * dL_dG;
-        scC += -0.5f * gdy * dy * dL_dG;
-        sop += G * dL_dalpha;
+        const f2 ex = __builtin_elementwise_fma(gdy, (f2){a.w, a.w}, gdx * a.z);   // -dG/d(delta x)
+        const f2 ey = __builtin_elementwise_fma(gdx, (f2){a.w, a.w}, gdy * b.x);   // -dG/d(delta y)
+        smx = __builtin_elementwise_fma(dL_dalpha, ex, smx);
+        smy = __builtin_elementwise_fma(dL_dalpha, ey, smy);
+        const f2 wx = gdx * dL_dalpha, wy = gdy * dL_dalpha;
+        scA = __builtin_elementwise_fma(wx, dx[p], scA);
+        scB = __builtin_elementwise_fma(wx, (f2){dy, dy}, scB);
+        scC = __builtin_elementwise_fma(wy, (f2){dy, dy}, scC);
+        sop = __builtin_elementwise_fma(G, dL_dalpha, sop);
       }
       if (__ballot(any) != 0ull) {  // wave-uniform: somebody in the tile saw this Gaussian
         touched |= 1ull << j;
         float t[9] = {sc[0].x + sc[0].y, sc[1].x + sc[1].y, sc[2].x + sc[2].y, sop.x + sop.y, scA.x + scA.y,
                       scB.x + scB.y, scC.x + scC.y, smx.x + smx.y, smy.x + smy.y};
         ggd_wave_sum9_to63(t);
-        const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5], t6 = t[6], t7 = t[7], t8 = t[8];
+        const float nho = -0.5f * b.y;   // d alpha / d G = opacity; d G / d conic = -1/2 G d d^T
+        const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = nho * t[4], t5 = nho * t[5], t6 = nho * t[6],
+                    t7 = (-b.y * ddelx_dx) * t[7], t8 = (-b.y * ddely_dy) * t[8];
         if (lane == 63) {
           float* o = s_sum + j * 9;
           o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = t5; o[6] = t6; o[7] = t7; o[8] = t8;
