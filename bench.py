@@ -149,13 +149,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  (GGD_BENCH_SHARE_GPU=1 is a test hook: several ranks on the visible devices round-robin with
+    # the gloo backend, to exercise the multi-rank control flow on a single-GPU box; never used for reported numbers.)
+    share = os.environ.get("GGD_BENCH_SHARE_GPU") == "1"
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if share else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from gaussian_gan_decoder_amd import _capi, rasterizer as R
     from gaussian_gan_decoder_amd.synthetic import make_scene, make_dL_dpix
