@@ -106,8 +106,12 @@ __device__ __forceinline__ void gelu_pack(const f4 (&acc)[2][8], bf16x8 (&bout)[
     }
 }
 
-// D-layout tile set (8 feature tiles x 2 point tiles, fp32) <-> row-major bf16 [point][128]: lane (j = point, g) holds
-// features 16*mt + 4g + r, i.e. 4 consecutive bf16 (8 bytes) of the point's row.
+// D-layout tile set (8 feature tiles x 2 point tiles, fp32) <-> bf16 [point][128] in the "Z layout": lane (j = point, g)
+// holds features 16*mt + 4g + r; inside every 32-feature block the row stores them at position
+//   zpos = 32*(mt/2) + 8*g + 4*(mt%2) + r        (true feature = 32*(mt/2) + 16*(mt%2) + 4*g + r)
+// so that a lane's two tiles of a block are 16 contiguous bytes and the four lanes of a point write 64 contiguous bytes
+// per instruction (the natural order gives 8-byte pieces, which lean on L2 write combining).  zbuf and dzbuf share the
+// layout; the weight-gradient kernel maps positions back to features when it writes dW / db.
 __device__ __forceinline__ void store_z(__bf16* __restrict__ zl, const f4 (&acc)[2][8], int64_t p0, int64_t cend,
                                         int lane) {
   const int j = lane & 15, g = lane >> 4;
@@ -116,11 +120,8 @@ __device__ __forceinline__ void store_z(__bf16* __restrict__ zl, const f4 (&acc)
     const int64_t pt = p0 + 16 * c + j;
     if (pt >= cend) continue;
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      bf16x4 v;
-      v[0] = (__bf16)acc[c][mt][0]; v[1] = (__bf16)acc[c][mt][1]; v[2] = (__bf16)acc[c][mt][2]; v[3] = (__bf16)acc[c][mt][3];
-      *reinterpret_cast<bf16x4*>(zl + pt * HID + 16 * mt + 4 * g) = v;
-    }
+    for (int k = 0; k < 4; ++k)   // Z layout (zpos): the lane's tiles 2k, 2k+1 as ONE 16-byte piece; 4 lanes = 64 B
+      *reinterpret_cast<bf16x8*>(zl + pt * HID + 32 * k + 8 * g) = pack8(acc[c][2 * k], acc[c][2 * k + 1]);
   }
 }
 
