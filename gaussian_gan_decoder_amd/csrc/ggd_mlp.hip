@@ -327,9 +327,9 @@ extern "C" int ggd_decoder_wgrad(ggd_ctx* ctx, void* stream, int32_t N, const vo
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
     ctx->attr_mask |= GGD_ATTR_MLP_WGRAD;
   }
-  // split-K: ~4 workgroups per CU over the 20 (head, layer) problems; at least 4 stages per workgroup
+  // split-K over up to 128 point chunks x 20 (head, layer) problems (measured: 32 -> 4.6 ms, 64 -> 3.9, 128 -> 3.7, 256 -> 3.9); at least 4 stages per workgroup
   int chunks = (N + 4 * WG_K - 1) / (4 * WG_K);
-  if (chunks > 64) chunks = 64;
+  if (chunks > 128) chunks = 128;
   if (chunks < 1) chunks = 1;
   hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(chunks, NHEAD * 4), dim3(WG_THREADS), WG_LDS,
                      static_cast<hipStream_t>(stream), N, 0, N, static_cast<const __bf16*>(zbuf),
@@ -369,7 +369,7 @@ extern "C" int ggd_decoder_backward_wgrad(ggd_ctx* ctx, void* stream, int32_t N,
                        static_cast<const unsigned char*>(packed_t), attrs, dattrs, static_cast<const __bf16*>(zbuf),
                        static_cast<__bf16*>(dzbuf), dout, dfeat, dinfo);
     int chunks = (n + 4 * WG_K - 1) / (4 * WG_K);
-    if (chunks > 64) chunks = 64;
+    if (chunks > 128) chunks = 128;
     if (chunks < 1) chunks = 1;
     hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(chunks, NHEAD * 4), dim3(WG_THREADS), WG_LDS, s, N, first, last,
                        static_cast<const __bf16*>(zbuf), static_cast<const __bf16*>(dzbuf), dout, feat, pos, attrs, wgrad);
