@@ -250,7 +250,7 @@ def main():
         out = step()
         bargs = (sc.bg, sc.xyz, out[2], empty, scales, rots, 1.0, empty, cam.world_view_transform,
                  cam.full_proj_transform, tanx, tany, g, shs, 0, cam.camera_center, out[3],
-                 R.rasterize_gaussians_native.last_layout_R, out[4], out[5], False)
+                 out[0], out[4], out[5], False)
         bacc: dict = {}
         for _ in range(5):
             R.rasterize_gaussians_backward_native(*bargs)

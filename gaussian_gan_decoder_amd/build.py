@@ -32,37 +32,62 @@ def _hipcc() -> str:
 
 
 def flags() -> list[str]:
-    return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+    return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
             "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics", "-fno-gpu-rdc",
             "-Wall", "-Wno-unused-function", "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC]
+
+
+OBJ_DIR = os.path.join(_PKG, "build")
+
+
+def _deps() -> list[str]:
+    return [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(_ROOT, "include", "ggd_raster.h"),
+                                                       os.path.abspath(__file__)]
 
 
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(_ROOT, "include", "ggd_raster.h"),
-                                                                 os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in [os.path.join(CSRC, f) for f in SOURCES] + _deps())
 
 
-def build(force: bool = False, save_temps: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return LIB_PATH
-    cmd = [_hipcc()] + flags() + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB_PATH]
+def _compile_one(src: str, force: bool, save_temps: bool, verbose: bool) -> tuple[str, bool]:
+    """One translation unit -> build/<name>.o (skipped when newer than the source and every header)."""
+    obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+    path = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj):
+        t = os.path.getmtime(obj)
+        if all(os.path.getmtime(d) <= t for d in [path] + _deps()):
+            return obj, False
+    cmd = [_hipcc()] + flags() + ["-c", path, "-o", obj]
     cwd = CSRC
     if save_temps:
-        tmp = os.path.join(_ROOT, "gpurun_out", "temps")
-        os.makedirs(tmp, exist_ok=True)
+        cwd = os.path.join(_ROOT, "gpurun_out", "temps")
+        os.makedirs(cwd, exist_ok=True)
         cmd.insert(1, "-save-temps")
-        cwd = tmp
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError(f"hipcc failed on {src}:\n" + res.stdout + res.stderr)
     if verbose and res.stderr.strip():
         print(res.stderr)
+    return obj, True
+
+
+def build(force: bool = False, save_temps: bool = False, verbose: bool = False) -> str:
+    """Per-file objects compiled in parallel (only the stale ones), then one link step."""
+    if not force and not is_stale():
+        return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(lambda f: _compile_one(f, force, save_temps, verbose), SOURCES))
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc"] + [o for o, _ in objs] + ["-o", LIB_PATH]
+    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     return LIB_PATH
 
 

@@ -51,10 +51,12 @@ extern "C" int ggd_geom_layout(int32_t P, ggd_geom_view* v) {
 extern "C" int ggd_binning_layout(int64_t R, ggd_binning_view* v) {
   if (!v || R < 0) return GGD_E_INVALID;
   size_t off = 0;
-  v->keys = off; off += ggd_align((size_t)R * sizeof(uint64_t));
+  // the sorted list comes first: it is the only part the backward reads, so its position does not depend on the R
+  // the buffer was laid out for (a capacity in the single-call forward, num_rendered in the two-call form)
   v->list = off; off += ggd_align((size_t)R * sizeof(uint32_t));
-  v->keys_alt = off; off += ggd_align((size_t)R * sizeof(uint64_t));
   v->list_alt = off; off += ggd_align((size_t)R * sizeof(uint32_t));
+  v->keys = off; off += ggd_align((size_t)R * sizeof(uint64_t));
+  v->keys_alt = off; off += ggd_align((size_t)R * sizeof(uint64_t));
   v->total = off;
   return GGD_OK;
 }

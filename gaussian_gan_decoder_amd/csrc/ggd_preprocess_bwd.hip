@@ -146,6 +146,9 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     const float len = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
     const float x = v0 / len, y = v1 / len, z = v2 / len;
     float ddir[3] = {0.0f, 0.0f, 0.0f};
+    // coefficients above the active degree (M > (deg+1)^2, e.g. max_sh_degree 3 with active degree 1) take no part
+    // in the colour: their gradient is zero and is written here (the caller does not pre-fill the arrays)
+    for (int k = 3 * (deg + 1) * (deg + 1); k < 3 * M; ++k) dsh[k] = 0.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float gcol = ((cl >> c) & 1u) ? 0.0f : gcol3[c];

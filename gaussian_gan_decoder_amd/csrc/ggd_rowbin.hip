@@ -82,7 +82,7 @@ __global__ __launch_bounds__(RB_THREADS) void rb_count1_kernel(int W, int H, con
 //      level 1: rows of one segment (all chunks);   level 2 is handled per row in rb_scan2_kernel.
 __global__ __launch_bounds__(1024) void rb_scan1_kernel(uint32_t* __restrict__ counts1,
                                                         const uint32_t* __restrict__ n_vis_ptr, int P,
-                                                        uint32_t* __restrict__ tab) {
+                                                        uint32_t* __restrict__ tab, uint32_t ent_cap) {
   __shared__ uint32_t part[16][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t n_vis = min((uint32_t)P, *n_vis_ptr);
@@ -108,7 +108,11 @@ __global__ __launch_bounds__(1024) void rb_scan1_kernel(uint32_t* __restrict__ c
     const uint32_t inc = wave_incl_scan_u32(tot);
     tab[RB_TAB_ROWSTART + lane] = inc - tot;
     if (lane == 63) tab[RB_TAB_ROWSTART + 64] = inc;
-    const uint32_t nblk = (tot + RB_CHUNK - 1) / RB_CHUNK;
+    // level-2 blocks cover only the entries that exist in `ent` (ent_cap of them): when a speculative forward
+    // under-estimated the capacity the rows are clamped, so that counts2 (sized for ent_cap) is never overrun
+    const uint32_t rs = inc - tot;
+    const uint32_t have = rs < ent_cap ? min(tot, ent_cap - rs) : 0u;
+    const uint32_t nblk = (have + RB_CHUNK - 1) / RB_CHUNK;
     const uint32_t binc = wave_incl_scan_u32(nblk);
     tab[RB_TAB_ROWBLK + lane] = binc - nblk;
     if (lane == 63) tab[RB_TAB_ROWBLK + 64] = binc;
@@ -372,7 +376,7 @@ int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const 
   const uint32_t nb2 = rb_blocks2(capacity);
   hipLaunchKernelGGL(rb_count1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, prm.width, prm.height, splat, order,
                      n_vis_ptr, prm.P, packed, counts1);
-  hipLaunchKernelGGL(rb_scan1_kernel, dim3(1), dim3(1024), 0, s, counts1, n_vis_ptr, prm.P, tab);
+  hipLaunchKernelGGL(rb_scan1_kernel, dim3(1), dim3(1024), 0, s, counts1, n_vis_ptr, prm.P, tab, capacity);
   hipLaunchKernelGGL(rb_scatter1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, packed, n_vis_ptr, prm.P, counts1, tab,
                      ent, capacity);
   hipLaunchKernelGGL(rb_count2_kernel, dim3(nb2), dim3(RB_THREADS), 0, s, ent, capacity, tab, counts2);

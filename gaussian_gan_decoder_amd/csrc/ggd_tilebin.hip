@@ -207,7 +207,10 @@ __global__ __launch_bounds__(TB_THREADS) void tilebin_scatter_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TbPool& sh = *reinterpret_cast<TbPool*>(smem);
   uint32_t* base = reinterpret_cast<uint32_t*>(smem + sizeof(TbPool));           // [T]
-  uint16_t* cnt = reinterpret_cast<uint16_t*>(smem + sizeof(TbPool) + (size_t)T * 4);  // [4][T]
+  // per-wave 16-bit counters [4][Ts]: the row stride is rounded to an even number of elements so that every row
+  // starts on a 32-bit boundary (sweep 1 adds into the 32-bit word holding a counter; an odd T would misalign it)
+  const int Ts = (T + 1) & ~1;
+  uint16_t* cnt = reinterpret_cast<uint16_t*>(smem + sizeof(TbPool) + (size_t)T * 4);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const uint32_t n_vis = min((uint32_t)P, *n_vis_ptr);
   const bool active = (uint32_t)blockIdx.x * TB_G < n_vis;
@@ -239,13 +242,13 @@ __global__ __launch_bounds__(TB_THREADS) void tilebin_scatter_kernel(
     }
   }
   if (!active) return;
-  for (int t = tid; t < 4 * T; t += TB_THREADS) cnt[t] = 0;
+  for (int t = tid; t < 4 * Ts; t += TB_THREADS) cnt[t] = 0;
   const uint32_t total = tb_load_pool(sh, blockIdx.x, n_vis, gx, gy, splat, tiles_touched, order);
   // each wave owns a contiguous quarter of the pooled list, rounded to whole rounds of 64
   const uint32_t quarter = ((total + 3u) / 4u + 63u) & ~63u;
   const uint32_t wbeg = min(total, (uint32_t)wv * quarter), wend = min(total, wbeg + quarter);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  uint16_t* mycnt = cnt + (size_t)wv * T;
+  uint16_t* mycnt = cnt + (size_t)wv * Ts;
 
   // sweep 1: per-wave tile counts -- order does not matter for counting, so one LDS atomic per instance on the
   // 32-bit word that holds the tile's 16-bit counter (counts <= 1024 never carry into the neighbour)
@@ -259,10 +262,10 @@ __global__ __launch_bounds__(TB_THREADS) void tilebin_scatter_kernel(
   {
     const uint32_t* row = prefix + (size_t)blockIdx.x * T;
     for (int t = tid; t < T; t += TB_THREADS) {
-      const uint32_t c0 = cnt[t], c1 = cnt[T + t], c2 = cnt[2 * T + t];
+      const uint32_t c0 = cnt[t], c1 = cnt[Ts + t], c2 = cnt[2 * Ts + t];
       base[t] += row[t];
-      cnt[t] = 0; cnt[T + t] = (uint16_t)c0; cnt[2 * T + t] = (uint16_t)(c0 + c1);
-      cnt[3 * T + t] = (uint16_t)(c0 + c1 + c2);
+      cnt[t] = 0; cnt[Ts + t] = (uint16_t)c0; cnt[2 * Ts + t] = (uint16_t)(c0 + c1);
+      cnt[3 * Ts + t] = (uint16_t)(c0 + c1 + c2);
     }
   }
   __syncthreads();
@@ -307,7 +310,7 @@ int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const
   int tbits = 0;
   while ((1 << tbits) < T) ++tbits;
   const size_t lds_count = sizeof(TbPool) + (size_t)T * 4;
-  const size_t lds_scatter = sizeof(TbPool) + (size_t)T * 4 + (size_t)T * 8;
+  const size_t lds_scatter = sizeof(TbPool) + (size_t)T * 4 + (size_t)((T + 1) & ~1) * 8;
   if (!(ctx->attr_mask & GGD_ATTR_TILEBIN)) {
     GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tilebin_count_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));

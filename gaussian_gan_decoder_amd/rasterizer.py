@@ -53,7 +53,9 @@ def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
     if t.device != device:
         raise ValueError(f"{name} is on {t.device}, expected {device} (all rasterizer inputs must share a device)")
     if t.dtype != torch.float32:
-        t = t.float()
+        # upstream's extension reads every tensor as float32; a silent cast would also make the fp32 gradients of the
+        # backward mismatch the leaf's dtype
+        raise TypeError(f"{name} must be float32 (got {t.dtype})")
     return t.contiguous()
 
 
@@ -89,9 +91,9 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
                                cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
                                sh, degree, campos, prefiltered, debug, raw_attributes=False):
     """== upstream `_C.rasterize_gaussians(...)`: returns
-    (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer).
-    `rasterize_gaussians_native.last_layout_R` is the value binningBuffer was laid out for (== num_rendered on the
-    two-phase path, the capacity on the single-call path); pass it as R to the backward."""
+    (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer).  binningBuffer may be larger than
+    num_rendered needs (single-call forward with a capacity hint); the sorted list sits at its offset 0 either way, so
+    the backward takes num_rendered as R exactly like upstream."""
     _require_cuda(means3D)
     dev = means3D.device
     if means3D.dim() != 2 or means3D.size(1) != 3:
@@ -128,7 +130,7 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
     hint = ctx.capacity_hint.get(key)
     with torch.cuda.device(dev):
         binning = None
-        if hint is not None and P > 0:
+        if hint is not None and P > 0 and not debug:   # debug: exact two-call form, buffers laid out for num_rendered
             # single-call forward: binning buffer sized from the previous frame of this shape (+25 %); the GPU does
             # not wait for the num_rendered round trip.  Falls through to the exact two-phase path on overflow.
             cap = int(hint * 1.25) + 65536
@@ -140,7 +142,6 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
                 binning = None
             else:
                 ctx.check(rc)
-                layout_R = cap
         else:
             ctx.check(lib.ggd_forward_geometry(ctx.handle, stream, C.byref(prm), _ptr(means3D), _ptr(sh_c),
                                                _ptr(col_c), _ptr(opacities), _ptr(sc_c), _ptr(rot_c), _ptr(cov_c),
@@ -149,9 +150,7 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
             binning = torch.empty((lib.ggd_binning_bytes(R.value),), **u8)
             ctx.check(lib.ggd_forward_render(ctx.handle, stream, C.byref(prm), _ptr(geom), R.value, _ptr(binning),
                                              _ptr(img), _ptr(color)))
-            layout_R = int(R.value)
     ctx.capacity_hint[key] = int(R.value)
-    rasterize_gaussians_native.last_layout_R = layout_R
     return int(R.value), color, radii, geom, binning, img
 
 
@@ -231,7 +230,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
             rs.campos, rs.prefiltered, rs.debug, getattr(rs, "raw_attributes", False))
         ctx.raster_settings = rs
-        ctx.num_rendered = rasterize_gaussians_native.last_layout_R   # what binningBuffer was laid out for
+        ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning,
                               img, opacities)
         ctx.mark_non_differentiable(radii)

@@ -93,7 +93,8 @@ typedef struct ggd_geom_view {
 
 typedef struct ggd_binning_view {
   size_t keys;     /* uint64[R] sorted keys:  (tile_id << 32) | depth_bits */
-  size_t list;     /* uint32[R] sorted Gaussian indices ("point_list") */
+  size_t list;     /* uint32[R] sorted Gaussian indices ("point_list"); ALWAYS at offset 0 of binning_buf, so readers of
+                      the list (the backward) do not need to know which R the buffer was laid out for */
   size_t keys_alt; /* uint64[R] ping-pong partner (contents unspecified after the call) */
   size_t list_alt; /* uint32[R] */
   size_t total;
@@ -147,8 +148,8 @@ int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* prm,
  * Forward in ONE call with a caller-chosen binning capacity (instances): geometry + render are enqueued back to back
  * and the host waits once at the end, so the GPU does not idle while num_rendered travels to the host (the two-phase
  * form above stalls the stream for that round trip).  binning_buf must hold ggd_binning_bytes(capacity).  Returns
- * GGD_E_CAPACITY (with *num_rendered set) when capacity < num_rendered: call again with a larger buffer.  The same
- * `capacity` must be passed as `num_rendered` to ggd_backward (it lays out binning_buf).  ggd_forward_can_speculate
+ * GGD_E_CAPACITY (with *num_rendered set) when capacity < num_rendered: call again with a larger buffer.  ggd_backward
+ * takes the returned num_rendered (the sorted list is at offset 0 of binning_buf for every capacity).  ggd_forward_can_speculate
  * tells whether the call will take the speculative route (tile-binning path) for that capacity.
  */
 int ggd_forward(ggd_ctx* ctx, void* stream, const ggd_params* prm,

@@ -26,7 +26,8 @@ class _Params(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("ggd_oracle.c", "ggd_oracle_impl.inc", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("ggd_oracle.c", "ggd_oracle_impl.inc", "ggd_oracle_bound.cpp",
+                                          "ggd_oracle_types.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-B", "libggd_oracle.so"], check=True, capture_output=True)
@@ -167,6 +168,72 @@ def backward(fwd: dict, dL_dpix):
     d_means2D[:, :2] = m2
     return dict(dL_dmeans2D=d_means2D, dL_dconic=co, dL_dopacity=d_opacity.astype(dt), dL_dcolors=dc,
                 dL_dmeans3D=d_means3D, dL_dcov3D=d_cov3D, dL_dsh=d_sh, dL_dscales=d_scales, dL_drots=d_rots)
+
+
+def backward_ref64(fwd: dict, dL_dpix, final_T=None, n_contrib=None, point_list=None, ranges=None):
+    """Reference for the GPU backward tests: fp32 decisions, fp64 values (ggo_render_backward_ref64 + the fp64 twin of
+    stage a11), and a per-element error budget.
+
+    `fwd` is an fp32 forward() dict.  final_T / n_contrib / point_list / ranges default to the oracle's own; the GPU
+    tests pass the buffers the HIP forward saved (what its backward consumes), so a threshold that flipped in the forward
+    does not enter the comparison of the backward.
+
+    Returns (ref, budget, fragile):
+      ref[name]    fp64 gradients, same names / shapes as backward()
+      budget[name] >= 0, same shapes, in units of eps32 = 2^-24: the conditioning S of the a10 sums (weighted sum of
+                   |terms|, see the C source) pushed through stage a11 by running error analysis
+                   (ggd_oracle_bound.cpp), so that   |fp32 result - ref| <= kappa * eps32 * budget   is the bound to test
+      fragile      uint32[P]: number of (pixel, Gaussian) pairs within 1e-6 of the alpha floor (see the C source)."""
+    L = lib()
+    assert fwd["dtype"] == np.float32
+    P, M, W, H = fwd["P"], fwd["M"], fwd["W"], fwd["H"]
+    prm = fwd["prm"]
+    g = _c(dL_dpix, np.float32, (3, H, W))
+    fT = _c(fwd["final_T"] if final_T is None else final_T, np.float32, (H, W))
+    nc = _c(fwd["n_contrib"] if n_contrib is None else n_contrib, np.uint32, (H, W))
+    pl = _c(fwd["point_list"] if point_list is None else point_list, np.uint32)
+    rg = _c(fwd["ranges"] if ranges is None else ranges, np.uint32, (-1, 2))
+    z = lambda *sh: np.zeros(sh, np.float64)
+    m2, co, dop, dc = z(P, 2), z(P, 3), z(P), z(P, 3)
+    Sm2, Sco, Sop, Sdc = z(P, 2), z(P, 3), z(P), z(P, 3)
+    fragile = np.zeros(P, np.uint32)
+    L.ggo_render_backward_ref64(C.byref(prm), _p(fwd["bg"]), _p(rg), _p(pl), _p(fwd["xy"]), _p(fwd["conic_opacity"]),
+                                _p(fwd["rgb"]), _p(fT), _p(nc), _p(g), _p(m2), _p(co), _p(dop), _p(dc),
+                                _p(Sm2), _p(Sco), _p(Sop), _p(Sdc), _p(fragile))
+    # stage a11 over the error-tracking number type (ggd_oracle_bound.cpp): value in double + running error bound in
+    # units of eps32.  Scene data enters with e = 0 (exact fp32 numbers), the a10 sums with e = their conditioning S;
+    # the discrete state (radii, clamped) is the fp32 forward's.
+    er = lambda a, e=None: None if a is None else np.ascontiguousarray(
+        np.stack([np.asarray(a, np.float64), np.zeros_like(a, np.float64) if e is None else e], axis=-1))
+    prm64 = _Params(P, M, fwd["sh_degree"], W, H, 0, float(prm.tanfovx), float(prm.tanfovy), float(prm.scale_modifier))
+    have_cp = fwd["colors_precomp"] is not None
+    have_c3 = fwd["cov3D_precomp"] is not None
+    view, proj, campos = er(fwd["viewmatrix"]), er(fwd["projmatrix"]), er(fwd["campos"])
+    means, shs = er(fwd["means3D"]), er(fwd["shs"])
+    scales, rots = er(fwd["scales"]), er(fwd["rotations"])
+    if have_c3:
+        cov = er(fwd["cov3D_precomp"])
+    else:  # Sigma with the rounding an fp32 evaluation of R S S R^T carries
+        cov = np.zeros((P, 6, 2), np.float64)
+        L.ggo_cov3d_all_err(P, _p(scales), C.c_double(float(prm.scale_modifier)), _p(rots), _p(cov))
+    radii, clamped = fwd["radii"], fwd["clamped"]
+    ze = lambda *sh: np.zeros(sh + (2,), np.float64)
+    d_means3D, d_cov3D = ze(P, 3), ze(P, 6)
+    d_sh = ze(P, max(M, 1), 3) if M > 0 else None
+    d_scales, d_rots = ze(P, 3), ze(P, 4)
+    L.ggo_preprocess_backward_err(C.byref(prm64), _p(view), _p(proj), _p(campos), _p(means), _p(shs), int(have_cp),
+                                  _p(scales), _p(rots), _p(cov), int(have_c3), _p(radii), _p(clamped),
+                                  _p(er(m2, Sm2)), _p(er(co, Sco)), _p(er(dc, Sdc)), _p(d_means3D), _p(d_cov3D),
+                                  _p(d_sh), _p(d_scales), _p(d_rots))
+    vis = (radii > 0)
+    outs = dict(dL_dmeans3D=d_means3D, dL_dcov3D=d_cov3D, dL_dsh=d_sh, dL_dscales=d_scales, dL_drots=d_rots)
+    ref = {k: (None if v is None else np.ascontiguousarray(v[..., 0])) for k, v in outs.items()}
+    budget = {k: (None if v is None else np.ascontiguousarray(v[..., 1])) for k, v in outs.items()}
+    d_means2D = z(P, 3); d_means2D[:, :2] = m2 * vis[:, None]
+    b_means2D = z(P, 3); b_means2D[:, :2] = Sm2 * vis[:, None]
+    ref.update(dL_dmeans2D=d_means2D, dL_dconic=co, dL_dopacity=dop * vis, dL_dcolors=dc * vis[:, None])
+    budget.update(dL_dmeans2D=b_means2D, dL_dconic=Sco, dL_dopacity=Sop * vis, dL_dcolors=Sdc * vis[:, None])
+    return ref, budget, fragile
 
 
 def mark_visible(means3D, viewmatrix):

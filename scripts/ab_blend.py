@@ -31,7 +31,7 @@ for (P, S, kind) in scenes:
                 out = R.rasterize_gaussians_native(*args); ts.append(ctx.stage_times()['blend'])
             ctx.set_profiling(False)
             torch.cuda.synchronize()
-            d = decode_buffers(P, S, S, out[0], out[3], out[4], out[5], R.rasterize_gaussians_native.last_layout_R)
+            d = decode_buffers(P, S, S, out[0], out[3], out[4], out[5])
             color = out[1].cpu().numpy()
             same = d['n_contrib'] == f['n_contrib']
             err = np.abs(color - f['color'])

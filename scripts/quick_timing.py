@@ -26,7 +26,7 @@ for (P, S, kind) in [(100000, 512, 'cube'), (1000000, 1024, 'cube'), (1000000, 1
     g = make_dL_dpix(S).to(dev)
     bargs = (sc.bg, sc.xyz, out[2], torch.empty(0, device=dev), sc.scales.contiguous(), sc.rotations.contiguous(), 1.0, torch.empty(0, device=dev),
              cam.world_view_transform, cam.full_proj_transform, math.tan(cam.FoVx*0.5), math.tan(cam.FoVy*0.5), g, sc.features_dc.contiguous(), 0, cam.camera_center,
-             out[3], R.rasterize_gaussians_native.last_layout_R, out[4], out[5], False)
+             out[3], out[0], out[4], out[5], False)
     for _ in range(3): R.rasterize_gaussians_backward_native(*bargs)
     torch.cuda.synchronize()
     st2 = ctx.stage_times()

@@ -22,7 +22,7 @@ for path in (2, 3):
 a, b = outs[2], outs[3]
 assert a[0] == b[0]
 assert torch.equal(a[1], b[1]), "images differ"
-lr = R.rasterize_gaussians_native.last_layout_R
+lr = a[0]
 bv = _capi.binning_view(lr)
 la = a[4][bv.list:bv.list + 4 * a[0]]; lb = b[4][bv.list:bv.list + 4 * a[0]]
 assert torch.equal(la, lb), "lists differ"

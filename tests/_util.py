@@ -10,12 +10,15 @@ from gaussian_gan_decoder_amd.synthetic import make_scene, make_dL_dpix
 
 
 def scene_inputs(P, size, kind="cube", seed=0, sh_degree=0, use_colors=False, use_cov=False, lsm=-6.0,
-                 fov_deg=12.0, width=None, height=None, scale_modifier=1.0, h=math.pi / 2, v=math.pi / 2):
-    """Returns a dict of CPU torch tensors / scalars describing one rasterizer call."""
+                 fov_deg=12.0, width=None, height=None, scale_modifier=1.0, h=math.pi / 2, v=math.pi / 2, sh_M=None):
+    """Returns a dict of CPU torch tensors / scalars describing one rasterizer call.
+    sh_M: number of SH coefficients stored per channel (>= (sh_degree+1)^2; default exactly that) -- the reference's
+    container always stores (max_sh_degree+1)^2 once the active degree is > 0 (gaussian_model.py:116-120)."""
     sc = make_scene(P, size, kind, seed=seed, log_scale_mean=lsm, fov_deg=fov_deg, h=h, v=v)
     cam = sc.cam
     g = torch.Generator().manual_seed(seed + 1000)
-    M = (sh_degree + 1) ** 2
+    M = (sh_degree + 1) ** 2 if sh_M is None else int(sh_M)
+    assert M >= (sh_degree + 1) ** 2
     shs = torch.cat([sc.features_dc, 0.3 * torch.randn(P, M - 1, 3, generator=g)], dim=1) if M > 1 else sc.features_dc
     W = width or size
     H = height or size
@@ -86,9 +89,8 @@ def run_native(d, device="cuda:0", debug=True, binning=None):
         t(d["bg"]), t(d["means3D"]), t(d["colors_precomp"]), t(d["opacities"]), t(d["scales"]), t(d["rotations"]),
         d["scale_modifier"], t(d["cov3D_precomp"]), t(d["viewmatrix"]), t(d["projmatrix"]), d["tanfovx"],
         d["tanfovy"], d["H"], d["W"], t(d["shs"]), d["sh_degree"], t(d["campos"]), False, debug)
-    layout_R = R.rasterize_gaussians_native.last_layout_R   # what `binning` was laid out for (>= num_rendered)
-    out = dict(num_rendered=num_rendered, layout_R=layout_R, color=color, radii=radii, geom=geom, binning=binning, img=img)
-    out.update(decode_buffers(d["P"], d["W"], d["H"], num_rendered, geom, binning, img, layout_R))
+    out = dict(num_rendered=num_rendered, color=color, radii=radii, geom=geom, binning=binning, img=img)
+    out.update(decode_buffers(d["P"], d["W"], d["H"], num_rendered, geom, binning, img))
     if debug and num_rendered > 0:
         ctx = _capi.context_for(dev)
         ku = torch.empty(num_rendered, dtype=torch.int64, device=dev)
@@ -102,9 +104,11 @@ def run_native(d, device="cuda:0", debug=True, binning=None):
     return out
 
 
-def decode_buffers(P, W, H, R, geom, binning, img, layout_R=None):
+def decode_buffers(P, W, H, R, geom, binning, img):
+    """`keys` is only meaningful when the forward ran with debug=True (radix-sort path, buffer laid out for exactly R);
+    the sorted list is at offset 0 of the binning buffer whatever capacity it was allocated for."""
     from gaussian_gan_decoder_amd import _capi
-    gv, bv, iv = _capi.geom_view(P), _capi.binning_view(R if layout_R is None else layout_R), _capi.img_view(W, H)
+    gv, bv, iv = _capi.geom_view(P), _capi.binning_view(R), _capi.img_view(W, H)
     g = geom.cpu().numpy(); b = binning.cpu().numpy(); im = img.cpu().numpy()
     T = ((W + 15) // 16) * ((H + 15) // 16)
     splat = g[gv.splat:gv.splat + 48 * P].view(np.float32).reshape(P, 12)
@@ -130,9 +134,59 @@ def run_native_backward(d, n, dL_dpix, device="cuda:0"):
     outs = R.rasterize_gaussians_backward_native(
         t(d["bg"]), t(d["means3D"]), n["radii"], t(d["colors_precomp"]), t(d["scales"]), t(d["rotations"]),
         d["scale_modifier"], t(d["cov3D_precomp"]), t(d["viewmatrix"]), t(d["projmatrix"]), d["tanfovx"],
-        d["tanfovy"], dL_dpix.to(dev), t(d["shs"]), d["sh_degree"], t(d["campos"]), n["geom"], n["layout_R"],
+        d["tanfovy"], dL_dpix.to(dev), t(d["shs"]), d["sh_degree"], t(d["campos"]), n["geom"], n["num_rendered"],
         n["binning"], n["img"], False)
     names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
              "dL_drots")
     torch.cuda.synchronize(dev)
     return {k: v.cpu().numpy() for k, v in zip(names, outs)}
+
+
+EPS32 = 2.0 ** -24
+ATOL = 1e-5      # the north_star's absolute bar
+KAPPA = 1.0      # safety factor on the fp32 error budget of the reference (oracle/ggd_oracle.py::backward_ref64)
+
+
+def backward_reference(d, o, n, dL_dpix):
+    """fp64 reference + per-element fp32 error budget for the backward of ONE forward: o = fp32 oracle forward of `d`,
+    n = run_native(d) (its saved final_T / n_contrib / list / ranges are what the HIP backward consumes, so they are
+    what the reference consumes too).  Asserts that the per-Gaussian state the backward reads is the oracle's."""
+    from oracle import ggd_oracle as O
+    vis = o["radii"] > 0
+    np.testing.assert_array_equal(n["radii"].cpu().numpy(), o["radii"])
+    np.testing.assert_array_equal(n["xy"][vis], o["xy"][vis])
+    np.testing.assert_array_equal(n["conic_opacity"][vis], o["conic_opacity"][vis])
+    np.testing.assert_array_equal(n["rgb"][vis], o["rgb"][vis])
+    return O.backward_ref64(o, np.asarray(dL_dpix, np.float32), final_T=n["final_T"], n_contrib=n["n_contrib"],
+                            point_list=n["point_list"], ranges=n["ranges"])
+
+
+def check_gradients(d, got: dict, ref: dict, budget: dict, fragile, kappa=KAPPA, report=None):
+    """|gpu - ref| <= ATOL + kappa * eps32 * budget for every element of every gradient array; Gaussians with a
+    (pixel, Gaussian) pair on the alpha floor (`fragile`) are left out, and their number is bounded."""
+    P = d["P"]
+    frag = fragile > 0
+    assert int(frag.sum()) <= max(4, P // 1000), f"{int(frag.sum())} Gaussians sit on the alpha floor"
+    worst = 0.0
+    for name, r in ref.items():
+        if name == "dL_dconic" or r is None:
+            continue
+        if name == "dL_dsh" and d["shs"] is None:
+            continue
+        if name in ("dL_dscales", "dL_drots") and d["scales"] is None:
+            continue
+        g = got[name].reshape(r.shape).astype(np.float64)
+        assert np.isfinite(g).all(), f"{name}: non-finite values (an element the library never wrote?)"
+        diff = np.abs(g - r)
+        tol = ATOL + kappa * EPS32 * budget[name]
+        ratio = diff / tol
+        ratio[frag] = 0.0
+        rel = diff / np.maximum(np.abs(r), 1e-30)
+        big = np.abs(r) >= 1e-3 * max(np.abs(r).max(), 1e-30)
+        if report is not None:
+            report.append(dict(array=name, max_abs_err=float(diff[~frag].max(initial=0.0)),
+                               max_rel_err_on_large=float(rel[big & ~frag.reshape((-1,) + (1,) * (r.ndim - 1))].max(initial=0.0)),
+                               max_abs_value=float(np.abs(r).max(initial=0.0)), worst_ratio=float(ratio.max(initial=0.0)),
+                               median_tol=float(np.median(tol))))
+        worst = max(worst, float(ratio.max(initial=0.0)))
+    return worst

@@ -113,3 +113,41 @@ def test_oracle_edge_cases():
                   rotations=np_(d["rotations"]), viewmatrix=np_(d["viewmatrix"]), projmatrix=np_(d["projmatrix"]),
                   campos=np_(d["campos"]), bg=np_(d["bg"]), W=32, H=32, tanfovx=d["tanfovx"], tanfovy=d["tanfovy"],
                   prefiltered=True)
+
+
+@pytest.mark.parametrize("case", [dict(P=4000, size=128, kind="shell", lsm=-5.0), dict(P=3000, size=96, sh_degree=2, sh_M=16, lsm=-4.5),
+                                  dict(P=2000, size=64, use_cov=True, use_colors=True, lsm=-4.0, scale_modifier=1.3),
+                                  "adversarial"], ids=str)
+def test_backward_reference_and_its_error_budget(case):
+    """backward_ref64 (fp32 decisions, fp64 values, running-error budget: the reference of the GPU backward tests):
+    (1) it states the same mathematics as the finite-difference-pinned fp64 twin -- evaluated on the same fp32 forward
+        state the two agree far inside the budget;
+    (2) the budget is a valid bound for an fp32 evaluation: the fp32 oracle backward lies inside it (with room: the
+        bound is worst-case, rounding errors add up like a random walk);
+    (3) it is not vacuous: the median budget of the large elements is below 1e-3 of their magnitude (1e-6 .. 2e-4
+        depending on how much the array cancels)."""
+    from _util import adversarial_inputs, EPS32, ATOL
+    d = adversarial_inputs() if case == "adversarial" else scene_inputs(**case)
+    g = make_dL_dpix(max(d["W"], d["H"]))[:, :d["H"], :d["W"]].contiguous().numpy()
+    o = run_oracle(d)
+    ref, bud, fragile = O.backward_ref64(o, g)
+    # (1) the fp64 twin's backward on the fp32 state (arrays upcast, discrete state shared)
+    o64 = dict(o)
+    for k, v in o.items():
+        if isinstance(v, np.ndarray) and v.dtype == np.float32:
+            o64[k] = v.astype(np.float64)
+    o64["dtype"] = np.dtype(np.float64)
+    twin = O.backward(o64, g.astype(np.float64))
+    b32 = O.backward(o, g)
+    ok = fragile == 0
+    for name, r in ref.items():
+        if r is None or twin.get(name) is None:
+            continue
+        tol = ATOL + EPS32 * bud[name]
+        t = np.abs(twin[name].reshape(r.shape) - r) / tol
+        f = np.abs(b32[name].reshape(r.shape).astype(np.float64) - r) / tol
+        assert t[ok].max(initial=0) <= 0.5, (name, "fp64 twin vs ref64", float(t[ok].max()))
+        assert f[ok].max(initial=0) <= 0.5, (name, "fp32 oracle outside the budget", float(f[ok].max()))
+        big = np.abs(r) > 0.01 * np.abs(r).max()
+        if big.any() and case != "adversarial":
+            assert np.median((EPS32 * bud[name])[big] / np.abs(r)[big]) < 1e-3, name   # (3)
