@@ -144,7 +144,8 @@ def run_native_backward(d, n, dL_dpix, device="cuda:0"):
 
 EPS32 = 2.0 ** -24
 ATOL = 1e-5      # the north_star's absolute bar
-KAPPA = 1.0      # safety factor on the fp32 error budget of the reference (oracle/ggd_oracle.py::backward_ref64)
+KAPPA = 0.25     # factor on the (worst-case) fp32 error budget of the reference (oracle/ggd_oracle.py::backward_ref64):
+                 # measured, the HIP backward sits at <= 0.11 and the fp32 CPU oracle at <= 0.15 of the budget itself
 
 
 def backward_reference(d, o, n, dL_dpix):
