@@ -31,7 +31,7 @@ class Params(C.Structure):
 
 
 class GeomView(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("splat", "tiles_touched", "point_offsets", "clamped", "depth_keys", "header", "total")]
+    _fields_ = [(n, C.c_size_t) for n in ("splat", "tiles_touched", "point_offsets", "clamped", "depth_keys", "rect", "header", "total")]
 
 
 class BinningView(C.Structure):
@@ -44,7 +44,7 @@ class ImgView(C.Structure):
 
 OPT_EXP_MODE, OPT_BLEND_CULL, OPT_BINNING, OPT_BLEND_SPLIT = 0, 1, 2, 3
 SPLAT_BYTES = 48
-SPLAT_FIELDS = ("x", "y", "conA", "conB", "conC", "opacity", "r", "g", "b", "depth", "radius", "tiles_touched")
+SPLAT_FIELDS = ("x", "y", "hA", "nB", "hC", "thr", "opacity", "r", "g", "b", "ex", "ey")
 
 _lib = None
 _lock = threading.Lock()

@@ -140,7 +140,8 @@ int launch_scan(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, uint32_t* out, 
 // ------------------------------------------------------------------------------------------------- duplicate --
 // 256 Gaussians per block.  LDS holds, per Gaussian of the block, the block-local exclusive instance offset,
 // the tile rect origin/width and the depth bits; lanes then walk the block's pooled instance list.
-__global__ __launch_bounds__(256) void duplicate_kernel(int P, int W, int H, const ggd_splat* __restrict__ splat,
+__global__ __launch_bounds__(256) void duplicate_kernel(int P, int W, int H, const uint2* __restrict__ rect,
+                                                        const uint32_t* __restrict__ depth_keys,
                                                         const uint32_t* __restrict__ tiles_touched,
                                                         const uint32_t* __restrict__ offsets,
                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
@@ -156,16 +157,13 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int W, int H, con
   if (i < P) { nt = tiles_touched[i]; inc = offsets[i]; }
   const uint32_t excl = inc - nt;
   if (tid == 0) s_base = excl;
-  const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+  const int gx = (W + 15) / 16;
   uint32_t origin = 0, width = 1, dbits = 0;
   if (nt > 0) {
-    const float4 a = reinterpret_cast<const float4*>(splat + i)[0];  // x, y, conA, conB
-    const float4 c = reinterpret_cast<const float4*>(splat + i)[2];  // b, depth, radius, tiles
-    int minx, miny, maxx, maxy;
-    ggd_tile_rect(a.x, a.y, __float_as_int(c.z), gx, gy, minx, miny, maxx, maxy);
-    origin = (uint32_t)minx | ((uint32_t)miny << 16);
-    width = (uint32_t)(maxx - minx);
-    dbits = __float_as_uint(c.y);
+    const uint2 rc = rect[i];   // {minx | maxx << 16, miny | maxy << 16}, written by the per-Gaussian stage
+    origin = (rc.x & 0xffffu) | ((rc.y & 0xffffu) << 16);
+    width = (rc.x >> 16) - (rc.x & 0xffffu);
+    dbits = depth_keys[i];
   }
   __syncthreads();
   const uint32_t base = s_base;
@@ -411,11 +409,11 @@ int ggd_launch_inclusive_scan(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, u
   return launch_scan<false>(ctx, s, in, out, n, d_total, tmp, tmp_bytes);
 }
 
-int ggd_launch_duplicate(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
+int ggd_launch_duplicate(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect, const uint32_t* depth_keys,
                          const uint32_t* tiles_touched, const uint32_t* offsets, uint64_t* keys, uint32_t* vals) {
   if (prm.P == 0) return GGD_OK;
   hipLaunchKernelGGL(duplicate_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, s, prm.P, prm.width, prm.height,
-                     splat, tiles_touched, offsets, keys, vals);
+                     rect, depth_keys, tiles_touched, offsets, keys, vals);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }

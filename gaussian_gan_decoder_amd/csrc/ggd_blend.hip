@@ -22,23 +22,6 @@ namespace {
 
 constexpr float ALPHA_FLOOR = 1.0f / 255.0f;
 
-struct TileGeom {
-  int tile, px0, py;
-  uint32_t lo, hi;
-};
-
-__device__ __forceinline__ TileGeom tile_geom(int gx, const uint32_t* __restrict__ ranges) {
-  TileGeom g;
-  g.tile = blockIdx.x;
-  const int tx = g.tile % gx, ty = g.tile / gx;
-  const int lane = threadIdx.x;
-  g.px0 = tx * 16 + (lane & 3) * 4;
-  g.py = ty * 16 + (lane >> 2);
-  const uint2 r = reinterpret_cast<const uint2*>(ranges)[g.tile];
-  g.lo = r.x; g.hi = r.y;
-  return g;
-}
-
 typedef float f2 __attribute__((ext_vector_type(2)));  // -> v_pk_{add,mul,fma}_f32: two pixels per VALU issue
 
 // power = -1/2 (A dx^2 + C dy^2) - B dx dy for a pixel PAIR, in the project's fixed operation order (same as the
@@ -76,56 +59,80 @@ __device__ __forceinline__ f2 blend_exp2v(f2 x) {
   return (f2){blend_exp<MODE>(x.x), blend_exp<MODE>(x.y)};
 }
 
-// Record-level pre-cull, done ONCE per staged record by the lane that gathers it (the per-pixel cull below costs every
-// lane of the wave ~15 instructions per record): the set {power >= thr} is the ellipse d^T Q d <= tau2 = -2 thr,
-// Q = [[A, B], [B, C]]; its axis-aligned extents are sqrt(tau2 * C / det), sqrt(tau2 * A / det).  If that box misses the
-// wave's pixel rectangle no pixel can pass the `power >= thr` test, so the record is never written to LDS.  The extents
-// are inflated by eps = 1e-3 + 4e-6 * trace^2 / det (covers the fp32 rounding of the in-loop power evaluation, whose
-// relative error grows with the anisotropy of Q) + 0.01 px; indefinite / NaN conics are kept.
-__device__ __forceinline__ bool record_box_hits(float x, float y, float A, float B, float C, float thr, float wx0,
-                                                float wx1, float wy0, float wy1) {
-  const float det = A * C - B * B;
-  const float tau2 = -2.0f * thr;
-  float ex = __builtin_huge_valf(), ey = __builtin_huge_valf();
-  if (det > 0.0f) {
-    const float s = tau2 / det;
-    const float tr = A + C;
-    const float infl = 1.001f + 4e-6f * (tr * tr) / det;
-    ex = __builtin_sqrtf(fmaxf(s * C, 0.0f)) * infl + 0.01f;
-    ey = __builtin_sqrtf(fmaxf(s * A, 0.0f)) * infl + 0.01f;
-  }
-  return !(tau2 < 0.0f) && !(x + ex < wx0 || x - ex > wx1 || y + ey < wy0 || y - ey > wy1);
+// Record-level pre-cull, done ONCE per gathered record by the lane that gathers it (the per-pixel cull costs every lane
+// of the wave ~13 issue slots per record): ggd_splat carries the half extents (ex, ey) of the axis-aligned box outside
+// of which power < thr, i.e. alpha < 1/255 (formed once per Gaussian by the preprocess kernel, with the fp32 safety
+// margins described there).  If that box misses the wave's pixel rectangle no pixel can pass the `power >= thr` test, so
+// the record is never written to LDS.  Comparisons with +inf (indefinite conic: always kept) / -inf (opacity < 1/255:
+// never kept) extents do the right thing.
+__device__ __forceinline__ bool record_box_hits(float x, float y, float ex, float ey, float wx0, float wx1, float wy0,
+                                                float wy1) {
+  return !(x + ex < wx0 || x - ex > wx1 || y + ey < wy0 || y - ey > wy1);
 }
 
-// Wave <-> pixel mapping of the blend kernels.  PXL = pixels per lane (horizontally adjacent):
-//   PXL = 4: one wave per 16x16 tile (lane = 4x1 pixels, 4 lanes per row, 16 rows);
-//   PXL = 2: two waves per tile, each a 16x8 half (lane = 2x1 pixels, 8 lanes per row, 8 rows) -- finer culling and
-//            earlier "all pixels done" exits, twice the waves (better latency hiding on small images).
-// The halves of one tile are T blocks apart so that both land on the same XCD (block b -> XCD b % 8) and share L2.
-template <int PXL>
+// Wave <-> pixel mapping of the blend kernels: a wave owns a BW x BH pixel block of a 16x16 tile, PXL horizontally
+// adjacent pixels per lane (BW / PXL lanes per row, BH = 64 * PXL / BW rows):
+//   PXL = 4, BW = 16: one wave per tile;      PXL = 2, BW = 16: two waves per tile (16x8 halves);
+//   PXL = 1, BW = 8 : four waves per tile (8x8 quarters).
+// The VALU cost of a blended record is proportional to the pixels a wave holds (packed fp32 brings no throughput on
+// gfx950), while a record typically reaches ~40 % of a 16x8 block: smaller blocks cull finer and leave fewer idle
+// lanes, at the price of more list scans.  The sub-blocks of one tile are T workgroups apart so that they land on the
+// same XCD (block b -> XCD b % 8) and share its L2.
+template <int PXL, int BW = 16>
 struct WaveGeom {
+  static constexpr int LPR = BW / PXL, BH = 64 / LPR, NSX = 16 / BW, NSUB = NSX * (16 / BH);
   int px0, py;
   uint32_t lo, hi;
   __device__ __forceinline__ WaveGeom(int gx, int T, const uint32_t* __restrict__ ranges, uint32_t capacity = 0xffffffffu) {
-    constexpr int LPR = 16 / PXL, ROWS = 64 / LPR;
     const int tile = (int)blockIdx.x % T, sub = (int)blockIdx.x / T;
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
-    px0 = tx * 16 + (lane % LPR) * PXL;
-    py = ty * 16 + sub * ROWS + lane / LPR;
+    px0 = tx * 16 + (sub % NSX) * BW + (lane % LPR) * PXL;
+    py = ty * 16 + (sub / NSX) * BH + lane / LPR;
     const uint2 r = reinterpret_cast<const uint2*>(ranges)[tile];
     lo = min(r.x, capacity); hi = min(r.y, capacity);  // capacity < R only in a speculative forward that is retried
   }
 };
 
+// Per-lane selects on WAVE-UNIFORM 64-bit lane masks held in SGPR pairs.  Measured on gfx950
+// (scripts/probes/valu_rate_probe.hip): v_cndmask_b32 in its VOP2 form (mask in VCC) issues at 1/8.7 of the v_fma_f32
+// rate, the VOP3 form with an SGPR-pair mask at 1/1.6 -- and hipcc picks the VOP2 form whenever the mask happens to
+// live in VCC.  Going through these helpers pins the VOP3 form and ties destination = old value (no copies where the
+// culled and the updated path of the record loop join).
+__device__ __forceinline__ void sel_into(float& dst, float src, uint64_t mask) {
+  asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(dst) : "v"(src), "s"(mask));
+}
+__device__ __forceinline__ void sel_into(uint32_t& dst, uint32_t src, uint64_t mask) {
+  asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(dst) : "v"(src), "s"(mask));
+}
+__device__ __forceinline__ float sel_or_zero(float src, uint64_t mask) {
+  float d;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(d) : "v"(src), "s"(mask));
+  return d;
+}
+// dst = mask ? src : dst, ordered after the computation of `after` (a value that still needs the OLD dst: keeps the
+// scheduler from sinking that use below the select, which would force a copy of the old value)
+__device__ __forceinline__ void sel_into_after(float& dst, float src, uint64_t mask, float after) {
+  asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(dst) : "v"(src), "s"(mask), "v"(after));
+}
+// acc += a * b in place (v_fmac_f32; through asm so that the SLP vectoriser does not pair the three colour channels
+// into v_pk_fma_f32 with register shuffles -- packed fp32 has no throughput advantage on gfx950)
+__device__ __forceinline__ void fma_into(float& acc, float a, float b) {
+  asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+}
+
 // Forward blend.  Per staged record:
-//   (1) the `power` values of the lane's pixels with packed fp32 math (operation order == the published form),
+//   (1) the `power` values of the lane's pixels (operation order == the published form),
 //   (2) CULL: if no pixel of the wave can reach alpha >= 1/255 -- tested in the power domain against a per-record
 //       threshold ln(1/(255*opacity)) lowered by a safety margin, so the decision is exact w.r.t. the float alpha
-//       test that follows -- the whole wave skips the record with one ballot, before any exp,
-//   (3) the exact per-pixel tests and the blend update.
+//       test that follows -- the whole wave skips the record before any exp,
+//   (3) the exact per-pixel tests and the blend update, branch-free: every condition is a wave-uniform 64-bit lane mask
+//       (v_cmp -> SGPR pair, combined on the scalar unit), every state update one select on such a mask.
 // A finished pixel gets x = +inf: its power becomes -inf/NaN and it drops out in (2) with no extra instructions.
-template <int EXP_MODE, bool CULL, int PXL>
+// Cost model (issue slots in units of one v_fma_f32, measured by the probe): plain VALU 1, packed fp32 1.85 (no
+// throughput gain over two plain ops on gfx950), v_cmp / VOP3 select / v_min 1.6, v_exp_f32 3.1: cull stage ~12 per
+// staged record, update ~55 per record that some pixel of the wave sees.
+template <int EXP_MODE, bool CULL, int PXL, int BW>
 __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx, int T,
                                                            const ggd_splat* __restrict__ splat,
                                                            const uint32_t* __restrict__ list,
@@ -135,112 +142,121 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
                                                            float* __restrict__ final_T,
                                                            uint32_t* __restrict__ n_contrib,
                                                            unsigned long long* __restrict__ stats) {
-  constexpr int NP = PXL / 2;  // pixel pairs per lane
   __shared__ float4 s_rec[64 * 3];
   const int lane = threadIdx.x;
-  const WaveGeom<PXL> g(gx, T, ranges, capacity);
+  using Geom = WaveGeom<PXL, BW>;
+  const Geom g(gx, T, ranges, capacity);
   const bool row_in = g.py < H;
-  const float INF = __builtin_huge_valf();
+  float INF = __builtin_huge_valf();
+  asm volatile("" : "+v"(INF));   // keep it in a VGPR (VOP3 selects take no 32-bit literal)
   uint32_t st_visited = 0, st_culled = 0, st_lanes = 0, st_pixels = 0;  // wave-uniform debug counters (GGD stats)
-  f2 Tr[NP], C[NP][3];  // per pixel PAIR: transmittance, accumulated colour
+  float Tr[PXL], C[PXL][3];   // per pixel: transmittance, accumulated colour
   uint32_t last[PXL];
-  f2 px[NP];  // pixel x coordinates; +inf once the pixel is finished / outside the image
-  int alive = 0;
+  float px[PXL];              // pixel x coordinates; +inf once the pixel is finished / outside the image
   const float pyf = (float)g.py;
 #pragma unroll
   for (int k = 0; k < PXL; ++k) {
-    if (k & 1) { Tr[k >> 1] = (f2){1.0f, 1.0f}; C[k >> 1][0] = C[k >> 1][1] = C[k >> 1][2] = (f2){0.0f, 0.0f}; }
+    Tr[k] = 1.0f; C[k][0] = C[k][1] = C[k][2] = 0.0f;
     last[k] = 0;
-    const bool in = row_in && (g.px0 + k) < W;
-    alive += in ? 1 : 0;
-    const float x = in ? (float)(g.px0 + k) : INF;
-    if (k & 1) px[k >> 1].y = x; else px[k >> 1].x = x;
+    px[k] = (row_in && (g.px0 + k) < W) ? (float)(g.px0 + k) : INF;
   }
+  auto wave_alive = [&]() {
+    uint64_t m = 0ull;
+#pragma unroll
+    for (int k = 0; k < PXL; ++k) m |= __ballot(px[k] < INF);
+    return m != 0ull;
+  };
 
   // the wave's pixel rectangle (pixel centres), for the record-level pre-cull
-  constexpr int LPR = 16 / PXL, ROWS = 64 / LPR;
-  const float wx0 = (float)(g.px0 - (lane % LPR) * PXL), wx1 = wx0 + 15.0f;
-  const float wy0 = (float)(g.py - lane / LPR), wy1 = wy0 + (float)(ROWS - 1);
+  const float wx0 = (float)(g.px0 - (lane % Geom::LPR) * PXL), wx1 = wx0 + (float)(BW - 1);
+  const float wy0 = (float)(g.py - lane / Geom::LPR), wy1 = wy0 + (float)(Geom::BH - 1);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-  float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+  // staged record (three 16-byte LDS words, read back as broadcasts), shuffled from the 48-byte ggd_splat so that the
+  // cull stage needs the first two words only:
+  //   q0 = {x, y, -A/2, -B}   q1 = {-C/2, power threshold, opacity, contributor index (1-based list position)}
+  //   q2 = {r, g, b, -}
+  float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
   bool keep = false;
   auto fetch = [&](uint32_t pos) {
     keep = false;
     if (pos < g.hi) {
       const float4* p = reinterpret_cast<const float4*>(splat + list[pos]);
-      r0 = p[0]; r1 = p[1]; r2 = p[2];
-      // record slot 2 is re-used for the blend: {b, power threshold, contributor index (1-based list position), -}
-      const float L = logf(1.0f / (255.0f * r1.y));
-      r2.y = CULL ? L - (2e-5f + 1e-6f * fabsf(L)) : -INF;
-      r2.z = __uint_as_float(pos - g.lo + 1u);
-      keep = CULL ? record_box_hits(r0.x, r0.y, r0.z, r0.w, r1.x, r2.y, wx0, wx1, wy0, wy1) : true;
+      const float4 r0 = p[0], r1 = p[1], r2 = p[2];   // x y hA nB | hC thr opacity r | g b ex ey
+      q0 = r0;
+      q1 = make_float4(r1.x, CULL ? r1.y : -__builtin_huge_valf(), r1.z, __uint_as_float(pos - g.lo + 1u));
+      q2 = make_float4(r1.w, r2.x, r2.y, 0.0f);
+      keep = CULL ? record_box_hits(r0.x, r0.y, r2.z, r2.w, wx0, wx1, wy0, wy1) : true;
     }
   };
   fetch(g.lo + lane);
-  bool finished = __ballot(alive != 0) == 0ull;
+  bool finished = !wave_alive();
   for (uint32_t base = g.lo; base < g.hi && !finished; base += 64) {
     __syncthreads();  // single-wave block: orders the previous round's LDS reads before this round's writes
     const uint64_t kept = __ballot(keep);
     if (keep) {  // compacted: only records whose box reaches this wave's pixels are staged
       const int slot = __popcll(kept & lt_mask);
-      s_rec[slot * 3 + 0] = r0; s_rec[slot * 3 + 1] = r1; s_rec[slot * 3 + 2] = r2;
+      s_rec[slot * 3 + 0] = q0; s_rec[slot * 3 + 1] = q1; s_rec[slot * 3 + 2] = q2;
     }
     st_visited += min(64u, g.hi - base);
     st_culled += min(64u, g.hi - base) - (uint32_t)__popcll(kept);
     fetch(base + 64 + lane);  // next round's gather is in flight while this round is blended
     __syncthreads();
     const int n = __popcll(kept);
-    for (int j = 0; j < n; ++j) {
-      if ((j & 7) == 0 && __ballot(alive != 0) == 0ull) { finished = true; break; }
-      const float4 a = s_rec[j * 3 + 0];  // x, y, conA, conB
-      const float4 b = s_rec[j * 3 + 1];  // conC, opacity, r, g
-      const float4 c = s_rec[j * 3 + 2];  // b, power threshold, contributor index
-      const float dy = a.y - pyf;
-      const float hA = -0.5f * a.z, nBdy = (-a.w) * dy, hCdy2 = ((-0.5f * b.x) * dy) * dy;
-      const f2 gxx = {a.x, a.x};
-      f2 pw[NP];
-      bool need[PXL];
-      bool lane_need = false;
+    // search-then-update: the inner loop only LOOKS for the next staged record that some pixel of the wave sees (no
+    // blend state is modified there), the update then runs as straight-line code of the outer loop -- so the blend
+    // state is an ordinary loop-carried value (with the update inside an `if` of a single loop the compiler computes it
+    // into fresh registers and copies ~10 of them back where the two paths join)
+    int j = 0;
+    while (true) {
+      float4 b, c;
+      float pw[PXL];
+      uint64_t need[PXL];
+      bool found = false;
+      while (j < n) {
+        if ((j & 7) == 0 && !wave_alive()) { finished = true; break; }
+        const float4 a = s_rec[j * 3 + 0];
+        b = s_rec[j * 3 + 1];
+        c = s_rec[j * 3 + 2];
+        const float dy = a.y - pyf;
+        const float nBdy = a.w * dy, hCdy2 = (b.x * dy) * dy;
+        uint64_t any = 0ull;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const f2 dx = gxx - px[p];
-        pw[p] = gauss_power2(hA, nBdy, hCdy2, dx);
-        need[2 * p] = pw[p].x >= c.y; need[2 * p + 1] = pw[p].y >= c.y;
-        lane_need = lane_need || need[2 * p] || need[2 * p + 1];
+        for (int k = 0; k < PXL; ++k) {
+          const float dx = a.x - px[k];
+          pw[k] = __builtin_fmaf(__builtin_fmaf(a.z, dx, nBdy), dx, hCdy2);
+          need[k] = __ballot(pw[k] >= b.y);
+          any |= need[k];
+        }
+        ++j;
+        if (any != 0ull) { found = true; break; }
+        st_culled += 1;
       }
-      const uint64_t need_lanes = __ballot(lane_need);
-      if (need_lanes == 0ull) { st_culled += 1; continue; }
+      if (!found) break;
       if (stats) {
-        st_lanes += (uint32_t)__popcll(need_lanes);
+        uint64_t lanes = 0ull;
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) st_pixels += (uint32_t)__popcll(__ballot(need[k]));
+        for (int k = 0; k < PXL; ++k) { lanes |= need[k]; st_pixels += (uint32_t)__popcll(need[k]); }
+        st_lanes += (uint32_t)__popcll(lanes);
       }
-      const uint32_t contributor = __float_as_uint(c.z);
+      const uint32_t contributor = __float_as_uint(b.w);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        // branch-free, packed update of a pixel pair.  alpha, the thresholds and T <- T (1 - alpha) are evaluated
-        // exactly as published; the colour is accumulated as fma(col, alpha * T, C) (one rounding fewer than
-        // (col * alpha) * T + C -- inside the 1e-5 tolerance, three packed FMAs for the pair instead of 18 scalar ops).
-        const f2 G = blend_exp2v<EXP_MODE>(pw[p]);
-        const f2 av = G * b.y;
-        const f2 alpha = {fminf(0.99f, av.x), fminf(0.99f, av.y)};
-        const bool live0 = need[2 * p] && !(pw[p].x > 0.0f) && !(alpha.x < ALPHA_FLOOR);
-        const bool live1 = need[2 * p + 1] && !(pw[p].y > 0.0f) && !(alpha.y < ALPHA_FLOOR);
-        const f2 test_T = Tr[p] * ((f2){1.0f, 1.0f} - alpha);
-        const bool low0 = test_T.x < 0.0001f, low1 = test_T.y < 0.0001f;
-        const bool stop0 = live0 && low0, stop1 = live1 && low1;
-        const bool upd0 = live0 && !low0, upd1 = live1 && !low1;
-        const f2 aT = alpha * Tr[p];
-        const f2 w = {upd0 ? aT.x : 0.0f, upd1 ? aT.y : 0.0f};
-        C[p][0] = __builtin_elementwise_fma((f2){b.z, b.z}, w, C[p][0]);
-        C[p][1] = __builtin_elementwise_fma((f2){b.w, b.w}, w, C[p][1]);
-        C[p][2] = __builtin_elementwise_fma((f2){c.x, c.x}, w, C[p][2]);
-        Tr[p] = (f2){upd0 ? test_T.x : Tr[p].x, upd1 ? test_T.y : Tr[p].y};
-        last[2 * p] = upd0 ? contributor : last[2 * p];
-        last[2 * p + 1] = upd1 ? contributor : last[2 * p + 1];
-        px[p] = (f2){stop0 ? INF : px[p].x, stop1 ? INF : px[p].y};
-        alive -= (stop0 ? 1 : 0) + (stop1 ? 1 : 0);
+      for (int k = 0; k < PXL; ++k) {
+        // alpha, the thresholds and T <- T (1 - alpha) are evaluated exactly as published; the colour is accumulated as
+        // fma(col, alpha * T, C) (one rounding fewer than (col * alpha) * T + C -- inside the 1e-5 tolerance)
+        const float G = blend_exp<EXP_MODE>(pw[k]);
+        const float alpha = fminf(0.99f, G * b.z);
+        const uint64_t live = need[k] & ~__ballot(pw[k] > 0.0f) & ~__ballot(alpha < ALPHA_FLOOR);
+        const float test_T = Tr[k] * (1.0f - alpha);
+        const uint64_t low = __ballot(test_T < 0.0001f);
+        const uint64_t upd = live & ~low, stop = live & low;
+        const float w = sel_or_zero(alpha * Tr[k], upd);
+        fma_into(C[k][0], c.x, w);
+        fma_into(C[k][1], c.y, w);
+        fma_into(C[k][2], c.z, w);
+        sel_into_after(Tr[k], test_T, upd, w);
+        sel_into(last[k], contributor, upd);
+        sel_into(px[k], INF, stop);
       }
     }
   }
@@ -258,37 +274,39 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
   const size_t pix0 = (size_t)g.py * W + g.px0;
   if (g.px0 + PXL - 1 < W && (W & 3) == 0) {
     if constexpr (PXL == 4) {
-      *reinterpret_cast<float4*>(final_T + pix0) = make_float4(Tr[0].x, Tr[0].y, Tr[NP - 1].x, Tr[NP - 1].y);
+      *reinterpret_cast<float4*>(final_T + pix0) = make_float4(Tr[0], Tr[1], Tr[2], Tr[3]);
       *reinterpret_cast<uint4*>(n_contrib + pix0) = make_uint4(last[0], last[1], last[2], last[3]);
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         const float bgc = ch == 0 ? bg0 : (ch == 1 ? bg1 : bg2);
         *reinterpret_cast<float4*>(out_color + ch * HW + pix0) = make_float4(
-            C[0][ch].x + Tr[0].x * bgc, C[0][ch].y + Tr[0].y * bgc, C[NP - 1][ch].x + Tr[NP - 1].x * bgc,
-            C[NP - 1][ch].y + Tr[NP - 1].y * bgc);
+            C[0][ch] + Tr[0] * bgc, C[1][ch] + Tr[1] * bgc, C[2][ch] + Tr[2] * bgc, C[3][ch] + Tr[3] * bgc);
       }
-    } else {
-      *reinterpret_cast<float2*>(final_T + pix0) = make_float2(Tr[0].x, Tr[0].y);
+    } else if constexpr (PXL == 2) {
+      *reinterpret_cast<float2*>(final_T + pix0) = make_float2(Tr[0], Tr[1]);
       *reinterpret_cast<uint2*>(n_contrib + pix0) = make_uint2(last[0], last[1]);
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         const float bgc = ch == 0 ? bg0 : (ch == 1 ? bg1 : bg2);
         *reinterpret_cast<float2*>(out_color + ch * HW + pix0) =
-            make_float2(C[0][ch].x + Tr[0].x * bgc, C[0][ch].y + Tr[0].y * bgc);
+            make_float2(C[0][ch] + Tr[0] * bgc, C[1][ch] + Tr[1] * bgc);
       }
+    } else {
+      final_T[pix0] = Tr[0];
+      n_contrib[pix0] = last[0];
+      out_color[pix0] = C[0][0] + Tr[0] * bg0;
+      out_color[HW + pix0] = C[0][1] + Tr[0] * bg1;
+      out_color[2 * HW + pix0] = C[0][2] + Tr[0] * bg2;
     }
   } else {
 #pragma unroll
     for (int k = 0; k < PXL; ++k) {
       if (g.px0 + k < W) {
-        const float Tk = (k & 1) ? Tr[k >> 1].y : Tr[k >> 1].x;
-        const float c0 = (k & 1) ? C[k >> 1][0].y : C[k >> 1][0].x, c1 = (k & 1) ? C[k >> 1][1].y : C[k >> 1][1].x,
-                    c2 = (k & 1) ? C[k >> 1][2].y : C[k >> 1][2].x;
-        final_T[pix0 + k] = Tk;
+        final_T[pix0 + k] = Tr[k];
         n_contrib[pix0 + k] = last[k];
-        out_color[pix0 + k] = c0 + Tk * bg0;
-        out_color[HW + pix0 + k] = c1 + Tk * bg1;
-        out_color[2 * HW + pix0 + k] = c2 + Tk * bg2;
+        out_color[pix0 + k] = C[k][0] + Tr[k] * bg0;
+        out_color[HW + pix0 + k] = C[k][1] + Tr[k] * bg1;
+        out_color[2 * HW + pix0 + k] = C[k][2] + Tr[k] * bg2;
       }
     }
   }
@@ -353,7 +371,7 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
   for (int d = 32; d >= 1; d >>= 1) maxn = max(maxn, (uint32_t)__shfl_xor((int)maxn, d, 64));
   if (maxn == 0) return;
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-  constexpr int LPR = 16 / PXL, ROWS = 64 / LPR;
+  constexpr int LPR = WaveGeom<PXL>::LPR, ROWS = WaveGeom<PXL>::BH;
   const float twx0 = (float)(g.px0 - (lane % LPR) * PXL), twy0 = (float)(g.py - lane / LPR);  // the wave's pixel rectangle
 
   uint32_t cend = g.lo + maxn;  // one past the last position that matters
@@ -366,13 +384,14 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
     if (lane < n) {
       const uint32_t my_id = list[cstart + lane];
       const float4* p = reinterpret_cast<const float4*>(splat + my_id);
-      q0 = p[0]; q1 = p[1]; q2 = p[2];
-      const float L = logf(1.0f / (255.0f * q1.y));  // same conservative power-domain threshold as the forward
-      // record slot 2: {b, power threshold, Gaussian id, 0-based list position}
-      q2.y = CULL ? L - (2e-5f + 1e-6f * fabsf(L)) : -__builtin_huge_valf();
-      q2.z = __uint_as_float(my_id);
-      q2.w = __uint_as_float((cstart - g.lo) + (uint32_t)lane);
-      keep = CULL ? record_box_hits(q0.x, q0.y, q0.z, q0.w, q1.x, q2.y, twx0, twx0 + 15.0f, twy0, twy0 + (float)(ROWS - 1)) : true;
+      const float4 r0 = p[0], r1 = p[1], r2 = p[2];   // x y hA nB | hC thr opacity r | g b ex ey
+      // staged as {x, y, A, B} {C, opacity, r, g} {b, power threshold, Gaussian id, 0-based list position}
+      // (A = -2 hA, B = -nB, C = -2 hC: exact)
+      q0 = make_float4(r0.x, r0.y, -2.0f * r0.z, -r0.w);
+      q1 = make_float4(-2.0f * r1.x, r1.z, r1.w, r2.x);
+      q2 = make_float4(r2.y, CULL ? r1.y : -__builtin_huge_valf(), __uint_as_float(my_id),
+                       __uint_as_float((cstart - g.lo) + (uint32_t)lane));
+      keep = CULL ? record_box_hits(r0.x, r0.y, r2.z, r2.w, twx0, twx0 + 15.0f, twy0, twy0 + (float)(ROWS - 1)) : true;
     }
     const uint64_t kept = __ballot(keep);
     const int nk = __popcll(kept);
@@ -499,16 +518,16 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
   const int em = ctx->opt[GGD_OPT_EXP_MODE];
   const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
   const int T = gx * gy;
-  const int split = ctx->opt[GGD_OPT_BLEND_SPLIT];
-  const bool two = split == 2 || (split == 1 && true);  // auto: two half-tile waves per tile
-#define GGD_LAUNCH_FWD(EM, CU)                                                                                      \
-  do {                                                                                                              \
-    if (two)                                                                                                        \
-      hipLaunchKernelGGL((blend_forward_kernel<EM, CU, 2>), dim3(2 * T), dim3(64), 0, s, prm.width, prm.height, gx, \
-                         T, splat, list, ranges, capacity, prm.bg, out_color, final_T, n_contrib, ctx->blend_stats); \
-    else                                                                                                            \
-      hipLaunchKernelGGL((blend_forward_kernel<EM, CU, 4>), dim3(T), dim3(64), 0, s, prm.width, prm.height, gx, T,  \
-                         splat, list, ranges, capacity, prm.bg, out_color, final_T, n_contrib, ctx->blend_stats);  \
+  const int split = ctx->opt[GGD_OPT_BLEND_SPLIT];   // 0: one wave per tile, 2: two (16x8), 3: four (8x8), 1: auto
+  const int nsub = split == 0 ? 1 : (split == 2 ? 2 : 4);
+#define GGD_LAUNCH_FWD1(EM, CU, PX, BWID)                                                                            \
+  hipLaunchKernelGGL((blend_forward_kernel<EM, CU, PX, BWID>), dim3(nsub * T), dim3(64), 0, s, prm.width, prm.height, \
+                     gx, T, splat, list, ranges, capacity, prm.bg, out_color, final_T, n_contrib, ctx->blend_stats)
+#define GGD_LAUNCH_FWD(EM, CU)                                                                                       \
+  do {                                                                                                               \
+    if (nsub == 4) GGD_LAUNCH_FWD1(EM, CU, 1, 8);                                                                    \
+    else if (nsub == 2) GGD_LAUNCH_FWD1(EM, CU, 2, 16);                                                              \
+    else GGD_LAUNCH_FWD1(EM, CU, 4, 16);                                                                             \
   } while (0)
   if (cull) {
     if (em == 0) GGD_LAUNCH_FWD(0, true); else if (em == 1) GGD_LAUNCH_FWD(1, true); else GGD_LAUNCH_FWD(2, true);
@@ -516,6 +535,7 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
     if (em == 0) GGD_LAUNCH_FWD(0, false); else if (em == 1) GGD_LAUNCH_FWD(1, false); else GGD_LAUNCH_FWD(2, false);
   }
 #undef GGD_LAUNCH_FWD
+#undef GGD_LAUNCH_FWD1
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }

@@ -44,6 +44,7 @@ extern "C" int ggd_geom_layout(int32_t P, ggd_geom_view* v) {
   v->point_offsets = off; off += ggd_align((size_t)P * sizeof(uint32_t));
   v->clamped = off; off += ggd_align((size_t)P);
   v->depth_keys = off; off += ggd_align((size_t)P * sizeof(uint32_t));
+  v->rect = off; off += ggd_align((size_t)P * 2 * sizeof(uint32_t));
   v->header = off; off += (P > 0 ? 256 : 0);
   v->total = off;
   return GGD_OK;
@@ -106,7 +107,7 @@ extern "C" ggd_ctx* ggd_create(int device) {
   ctx->device = device;
   if (const char* e = getenv("GGD_EXP_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->opt[GGD_OPT_EXP_MODE] = v; }
   if (const char* e = getenv("GGD_BINNING")) { const int v = atoi(e); if (v >= 0 && v <= 3) ctx->opt[GGD_OPT_BINNING] = v; }
-  if (const char* e = getenv("GGD_BLEND_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->opt[GGD_OPT_BLEND_SPLIT] = v; }
+  if (const char* e = getenv("GGD_BLEND_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 3) ctx->opt[GGD_OPT_BLEND_SPLIT] = v; }
   if (const char* e = getenv("GGD_BLEND_CULL")) ctx->opt[GGD_OPT_BLEND_CULL] = atoi(e) != 0;
   int prev = 0;
   (void)hipGetDevice(&prev);
@@ -140,7 +141,7 @@ extern "C" const char* ggd_last_error(ggd_ctx* ctx) { return ctx ? ctx->err.c_st
 
 extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
   if (!ctx) return GGD_E_INVALID;
-  static const int kMax[GGD_OPT_COUNT] = {2, 1, 3, 2};
+  static const int kMax[GGD_OPT_COUNT] = {2, 1, 3, 3};
   if (option < 0 || option >= GGD_OPT_COUNT || value < 0 || value > kMax[option])
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_set_option: unknown option or value");
   ctx->opt[option] = value;
@@ -239,6 +240,7 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
   uint32_t* offsets = reinterpret_cast<uint32_t*>(gb + gv.point_offsets);
   uint8_t* clamped = reinterpret_cast<uint8_t*>(gb + gv.clamped);
   uint32_t* depth_keys = reinterpret_cast<uint32_t*>(gb + gv.depth_keys);
+  uint2* rect = reinterpret_cast<uint2*>(gb + gv.rect);
   uint32_t* header = reinterpret_cast<uint32_t*>(gb + gv.header);
 
   const size_t scan_tmp = ggd_scan_tmp_bytes(prm->P);
@@ -249,7 +251,7 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
   {
     StageTimer t(ctx, ST_PREPROCESS, s);
     rc = ggd_launch_preprocess(ctx, s, *prm, means3D, shs, colors_precomp, opacities, scales, rotations,
-                               cov3D_precomp, splat, tiles, shs ? clamped : nullptr, radii, depth_keys, header,
+                               cov3D_precomp, splat, tiles, shs ? clamped : nullptr, radii, depth_keys, rect, header,
                                ctx->d_words + 1);
     if (rc != GGD_OK) return rc;
   }
@@ -304,6 +306,8 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
   const ggd_splat* splat = reinterpret_cast<const ggd_splat*>(gb + gv.splat);
   const uint32_t* tiles = reinterpret_cast<const uint32_t*>(gb + gv.tiles_touched);
   const uint32_t* offsets = reinterpret_cast<const uint32_t*>(gb + gv.point_offsets);
+  const uint2* rect = reinterpret_cast<const uint2*>(gb + gv.rect);
+  const uint32_t* depth_keys_all = reinterpret_cast<const uint32_t*>(gb + gv.depth_keys);
   uint64_t* keys = reinterpret_cast<uint64_t*>(bb + bv.keys);
   uint32_t* list = reinterpret_cast<uint32_t*>(bb + bv.list);
   uint64_t* keys_alt = reinterpret_cast<uint64_t*>(bb + bv.keys_alt);
@@ -347,8 +351,8 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
       StageTimer t(ctx, ST_DUPLICATE, s);
       // the depth sort dropped the culled Gaussians (key 0xFFFFFFFF) and left the number of kept ones on the device
       const uint32_t* n_vis = ggd_sort32_nvalid_ptr(tmp);
-      rc = rowbin ? ggd_launch_rowbin(ctx, s, *prm, splat, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp)
-                  : ggd_launch_tilebin(ctx, s, *prm, splat, tiles, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp);
+      rc = rowbin ? ggd_launch_rowbin(ctx, s, *prm, rect, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp)
+                  : ggd_launch_tilebin(ctx, s, *prm, rect, tiles, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp);
       if (rc != GGD_OK) return rc;
     }
   } else {
@@ -361,7 +365,7 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
     uint32_t* v0 = to_alt ? list_alt : list;
     {
       StageTimer t(ctx, ST_DUPLICATE, s);
-      rc = ggd_launch_duplicate(ctx, s, *prm, splat, tiles, offsets, k0, v0);
+      rc = ggd_launch_duplicate(ctx, s, *prm, rect, depth_keys_all, tiles, offsets, k0, v0);
       if (rc != GGD_OK) return rc;
     }
     if (prm->debug) {

@@ -68,15 +68,16 @@ int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, co
                           const float* shs, const float* colors_precomp, const float* opacities,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           ggd_splat* splat, uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii,
-                          uint32_t* depth_keys, uint32_t* visible_count, uint32_t* trap_flag);
+                          uint32_t* depth_keys, uint2* rect, uint32_t* visible_count, uint32_t* trap_flag);
 int ggd_launch_mark_visible(ggd_ctx* ctx, hipStream_t s, int P, const float* means3D, const float* view,
                             uint8_t* present);
 // inclusive scan of a uint32 array; total written to *d_total (device)
 int ggd_launch_inclusive_scan(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, uint32_t* out, int64_t n,
                               uint32_t* d_total, void* tmp, size_t tmp_bytes);
 size_t ggd_scan_tmp_bytes(int64_t n);
-int ggd_launch_duplicate(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
-                         const uint32_t* tiles_touched, const uint32_t* offsets, uint64_t* keys, uint32_t* vals);
+int ggd_launch_duplicate(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect,
+                         const uint32_t* depth_keys, const uint32_t* tiles_touched, const uint32_t* offsets,
+                         uint64_t* keys, uint32_t* vals);
 size_t ggd_sort_tmp_bytes(int64_t n);
 size_t ggd_sort32_tmp_bytes(int64_t n);
 const uint32_t* ggd_sort32_nvalid_ptr(const void* tmp);  // device word: keys kept by ggd_launch_sort32_iota
@@ -92,12 +93,12 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
 // Tile binning (GGD_OPT_BINNING = 1): sorted Gaussian order -> per-tile lists + ranges.
 bool ggd_rowbin_supported(int W, int H);
 size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity);
-int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat, const uint32_t* order,
+int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect, const uint32_t* order,
                       const uint32_t* n_vis_ptr, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
                       size_t tmp_bytes);
 bool ggd_tilebin_supported(int T);
 size_t ggd_tilebin_tmp_bytes(int P, int T);
-int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
+int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect,
                        const uint32_t* tiles_touched, const uint32_t* order, const uint32_t* n_vis_ptr,
                        uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp, size_t tmp_bytes);
 int ggd_launch_ranges(ggd_ctx* ctx, hipStream_t s, const uint64_t* keys, int64_t n, uint32_t* ranges, int T);

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, ggd_splat* __restrict__ splat, uint32_t* __restrict__ tiles_touched,
     uint8_t* __restrict__ clamped, int32_t* __restrict__ radii, uint32_t* __restrict__ depth_keys,
-    uint32_t* __restrict__ visible_count, uint32_t* __restrict__ trap_flag) {
+    uint2* __restrict__ rect, uint32_t* __restrict__ trap_flag) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   const Mat16 V = load_mat(view);
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   bool visible = false;
   ggd_splat out;
   uint32_t clamp_bits = 0;
+  uint2 rect_out = make_uint2(0u, 0u);
 
   if (t[2] > 0.2f) {
     float h[4];
@@ -89,13 +90,34 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
           const float campos[3] = {campos_p[0], campos_p[1], campos_p[2]};
           sh_to_rgb(deg, shs + (size_t)i * M * 3, p, campos, rgb, clamp_bits);
         }
+        rect_out = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16), (uint32_t)miny | ((uint32_t)maxy << 16));
+        const float conA = c * det_inv, conB = -b * det_inv, conC = a * det_inv;   // the published conic
+        const float opac = raw ? act_sigmoid(opacities[i]) : opacities[i];
         out.x = px; out.y = py;
-        out.conA = c * det_inv; out.conB = -b * det_inv; out.conC = a * det_inv;
-        out.opacity = raw ? act_sigmoid(opacities[i]) : opacities[i];
+        out.hA = -0.5f * conA; out.nB = -conB; out.hC = -0.5f * conC;   // exact rescalings (see ggd_raster.h)
+        out.opacity = opac;
         out.r = rgb[0]; out.g = rgb[1]; out.b = rgb[2];
-        out.depth = t[2];
-        out.radius = irad;
-        out.tiles_touched = ntiles;
+        // Blend-side culling data, once per Gaussian (the blend kernels used to derive it once per (tile, Gaussian)):
+        // alpha = opacity * exp(power) >= 1/255  <=>  power >= L = ln(1 / (255 opacity)); thr sits a safety margin below L so
+        // that the decision is exact w.r.t. the float alpha test that follows.  {power >= thr} is the ellipse
+        // d^T Q d <= tau2 = -2 thr, Q = [[A, B], [B, C]]; its axis-aligned half extents are sqrt(tau2 C / det),
+        // sqrt(tau2 A / det), inflated by 1.001 + 4e-6 trace^2 / det (the fp32 rounding of the in-loop power evaluation
+        // grows with the anisotropy of Q) + 0.01 px.  Indefinite / NaN conics get +inf (never culled by the box);
+        // thr > 0 (opacity < 1/255) can never be reached by power <= 0: the box is empty (extents -inf).
+        const float L = logf(1.0f / (255.0f * opac));
+        const float thr = L - (2e-5f + 1e-6f * fabsf(L));
+        const float cdet = conA * conC - conB * conB;
+        const float tau2 = -2.0f * thr;
+        float ex = __builtin_huge_valf(), ey = __builtin_huge_valf();
+        if (cdet > 0.0f) {
+          const float sdet = tau2 / cdet;
+          const float tr = conA + conC;
+          const float infl = 1.001f + 4e-6f * (tr * tr) / cdet;
+          ex = __builtin_sqrtf(fmaxf(sdet * conC, 0.0f)) * infl + 0.01f;
+          ey = __builtin_sqrtf(fmaxf(sdet * conA, 0.0f)) * infl + 0.01f;
+        }
+        if (tau2 < 0.0f) { ex = -__builtin_huge_valf(); ey = -__builtin_huge_valf(); }
+        out.thr = thr; out.ex = ex; out.ey = ey;
       }
     }
   } else if (prefiltered) {
@@ -105,7 +127,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   radii[i] = irad;
   tiles_touched[i] = ntiles;
   depth_keys[i] = visible ? __float_as_uint(t[2]) : 0xFFFFFFFFu;
-  (void)visible_count;
+  rect[i] = rect_out;
   if (clamped) clamped[i] = (uint8_t)clamp_bits;
   if (visible) {
     float4* dst = reinterpret_cast<float4*>(splat + i);
@@ -130,13 +152,14 @@ int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, co
                           const float* shs, const float* colors_precomp, const float* opacities,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           ggd_splat* splat, uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii,
-                          uint32_t* depth_keys, uint32_t* visible_count, uint32_t* trap_flag) {
+                          uint32_t* depth_keys, uint2* rect, uint32_t* visible_count, uint32_t* trap_flag) {
+  (void)visible_count;
   if (prm.P == 0) return GGD_OK;
   const int grid = (prm.P + 255) / 256;
   hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, s, prm.P, prm.M, prm.sh_degree, prm.width,
                      prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.raw_attributes, prm.viewmatrix,
                      prm.projmatrix, prm.campos, means3D, shs, colors_precomp, opacities, scales, rotations,
-                     cov3D_precomp, splat, tiles_touched, clamped, radii, depth_keys, visible_count, trap_flag);
+                     cov3D_precomp, splat, tiles_touched, clamped, radii, depth_keys, rect, trap_flag);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }

@@ -48,7 +48,7 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
 }
 
 // ---- level 1 count: rect of every depth-ordered Gaussian (kept, packed, for the scatter) + per-row counts of the chunk
-__global__ __launch_bounds__(RB_THREADS) void rb_count1_kernel(int W, int H, const ggd_splat* __restrict__ splat,
+__global__ __launch_bounds__(RB_THREADS) void rb_count1_kernel(int W, int H, const uint2* __restrict__ rect,
                                                                const uint32_t* __restrict__ order,
                                                                const uint32_t* __restrict__ n_vis_ptr, int P,
                                                                uint2* __restrict__ packed, uint32_t* __restrict__ counts1) {
@@ -56,7 +56,6 @@ __global__ __launch_bounds__(RB_THREADS) void rb_count1_kernel(int W, int H, con
   const uint32_t n_vis = min((uint32_t)P, *n_vis_ptr);
   const uint32_t base = (uint32_t)blockIdx.x * RB_CHUNK;
   if (base >= n_vis) return;
-  const int gx = (W + 15) / 16, gy = (H + 15) / 16;
   const int tid = threadIdx.x;
   if (tid < 65) diff[tid] = 0;
   __syncthreads();
@@ -65,10 +64,9 @@ __global__ __launch_bounds__(RB_THREADS) void rb_count1_kernel(int W, int H, con
     const uint32_t rnk = base + (uint32_t)q * RB_THREADS + tid;
     if (rnk < n_vis) {
       const uint32_t id = order[rnk];
-      const float4 a = reinterpret_cast<const float4*>(splat + id)[0];  // x, y, conA, conB
-      const float4 c = reinterpret_cast<const float4*>(splat + id)[2];  // b, depth, radius, tiles
-      int x0, y0, x1, y1;
-      const int n = ggd_tile_rect(a.x, a.y, __float_as_int(c.z), gx, gy, x0, y0, x1, y1);
+      const uint2 rc = rect[id];   // {minx | maxx << 16, miny | maxy << 16} (grids up to 64 x 64 here)
+      int x0 = (int)(rc.x & 0xffffu), x1 = (int)(rc.x >> 16), y0 = (int)(rc.y & 0xffffu), y1 = (int)(rc.y >> 16);
+      const int n = (x1 - x0) * (y1 - y0);
       if (n <= 0) { x0 = x1 = y0 = y1 = 0; }
       packed[rnk] = make_uint2(id, (uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)y0 << 16) | ((uint32_t)y1 << 24));
       if (n > 0) { atomicAdd(&diff[y0], 1); atomicAdd(&diff[y1], -1); }
@@ -360,7 +358,7 @@ size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity) {
 }
 
 // capacity: upper bound on num_rendered (the level-1 entry count is <= num_rendered); order = depth-sorted ids.
-int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat, const uint32_t* order,
+int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect, const uint32_t* order,
                       const uint32_t* n_vis_ptr, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
                       size_t tmp_bytes) {
   if (!ggd_rowbin_supported(prm.width, prm.height)) return ggd_fail(ctx, GGD_E_INVALID, "tile grid too large for row binning");
@@ -374,7 +372,7 @@ int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const 
   uint32_t* counts2 = reinterpret_cast<uint32_t*>(p);
   const int nb1 = rb_blocks1(prm.P);
   const uint32_t nb2 = rb_blocks2(capacity);
-  hipLaunchKernelGGL(rb_count1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, prm.width, prm.height, splat, order,
+  hipLaunchKernelGGL(rb_count1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, prm.width, prm.height, rect, order,
                      n_vis_ptr, prm.P, packed, counts1);
   hipLaunchKernelGGL(rb_scan1_kernel, dim3(1), dim3(1024), 0, s, counts1, n_vis_ptr, prm.P, tab, capacity);
   hipLaunchKernelGGL(rb_scatter1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, packed, n_vis_ptr, prm.P, counts1, tab,

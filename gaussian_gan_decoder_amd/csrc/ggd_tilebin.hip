@@ -45,7 +45,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 
 // Fill the pool for block `blk`; returns the number of instances of the block.
 __device__ __forceinline__ uint32_t tb_load_pool(TbPool& sh, int blk, uint32_t n_vis, int gx, int gy,
-                                                 const ggd_splat* __restrict__ splat,
+                                                 const uint2* __restrict__ rect,
                                                  const uint32_t* __restrict__ tiles_touched,
                                                  const uint32_t* __restrict__ order) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -59,12 +59,9 @@ __device__ __forceinline__ uint32_t tb_load_pool(TbPool& sh, int blk, uint32_t n
       id = order[rnk];
       n = tiles_touched[id];
       if (n > 0) {
-        const float4 a = reinterpret_cast<const float4*>(splat + id)[0];  // x, y, conA, conB
-        const float4 c = reinterpret_cast<const float4*>(splat + id)[2];  // b, depth, radius, tiles
-        int minx, miny, maxx, maxy;
-        ggd_tile_rect(a.x, a.y, __float_as_int(c.z), gx, gy, minx, miny, maxx, maxy);
-        origin = (uint32_t)minx | ((uint32_t)miny << 16);
-        width = (uint32_t)(maxx - minx);
+        const uint2 rc = rect[id];   // {minx | maxx << 16, miny | maxy << 16}
+        origin = (rc.x & 0xffffu) | ((rc.y & 0xffffu) << 16);
+        width = (rc.x >> 16) - (rc.x & 0xffffu);
       }
     }
     nt[q] = n; sum += n;
@@ -141,7 +138,7 @@ __device__ __forceinline__ void tb_for_rounds(TbPool& sh, uint32_t wbeg, uint32_
   }
 }
 
-__global__ __launch_bounds__(TB_THREADS) void tilebin_count_kernel(int W, int H, const ggd_splat* __restrict__ splat,
+__global__ __launch_bounds__(TB_THREADS) void tilebin_count_kernel(int W, int H, const uint2* __restrict__ rect,
                                                                    const uint32_t* __restrict__ tiles_touched,
                                                                    const uint32_t* __restrict__ order,
                                                                    const uint32_t* __restrict__ n_vis_ptr, int P,
@@ -153,7 +150,7 @@ __global__ __launch_bounds__(TB_THREADS) void tilebin_count_kernel(int W, int H,
   if ((uint32_t)blockIdx.x * TB_G >= n_vis) return;
   const int gx = (W + 15) / 16, gy = (H + 15) / 16;
   for (int t = threadIdx.x; t < T; t += TB_THREADS) hist[t] = 0;
-  const uint32_t total = tb_load_pool(sh, blockIdx.x, n_vis, gx, gy, splat, tiles_touched, order);
+  const uint32_t total = tb_load_pool(sh, blockIdx.x, n_vis, gx, gy, rect, tiles_touched, order);
   {
     const int wv = threadIdx.x >> 6;
     const uint32_t quarter = ((total + 3u) / 4u + 63u) & ~63u;
@@ -200,7 +197,7 @@ __global__ __launch_bounds__(64 * TS_WAVES) void tilebin_scan_kernel(uint32_t* _
 }
 
 __global__ __launch_bounds__(TB_THREADS) void tilebin_scatter_kernel(
-    int W, int H, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ tiles_touched,
+    int W, int H, const uint2* __restrict__ rect, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ order, const uint32_t* __restrict__ n_vis_ptr, int P,
     const uint32_t* __restrict__ prefix /*[nb][T]*/, const uint32_t* __restrict__ totals, int T, int tbits,
     uint32_t* __restrict__ list, uint32_t* __restrict__ ranges, uint32_t capacity) {
@@ -243,7 +240,7 @@ __global__ __launch_bounds__(TB_THREADS) void tilebin_scatter_kernel(
   }
   if (!active) return;
   for (int t = tid; t < 4 * Ts; t += TB_THREADS) cnt[t] = 0;
-  const uint32_t total = tb_load_pool(sh, blockIdx.x, n_vis, gx, gy, splat, tiles_touched, order);
+  const uint32_t total = tb_load_pool(sh, blockIdx.x, n_vis, gx, gy, rect, tiles_touched, order);
   // each wave owns a contiguous quarter of the pooled list, rounded to whole rounds of 64
   const uint32_t quarter = ((total + 3u) / 4u + 63u) & ~63u;
   const uint32_t wbeg = min(total, (uint32_t)wv * quarter), wend = min(total, wbeg + quarter);
@@ -298,7 +295,7 @@ size_t ggd_tilebin_tmp_bytes(int P, int T) {
   return ggd_align((size_t)tb_blocks(P) * T * sizeof(uint32_t)) + ggd_align((size_t)T * sizeof(uint32_t));
 }
 
-int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
+int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect,
                        const uint32_t* tiles_touched, const uint32_t* order, const uint32_t* n_vis_ptr,
                        uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp, size_t tmp_bytes) {
   const int T = ((prm.width + 15) / 16) * ((prm.height + 15) / 16);
@@ -318,10 +315,10 @@ int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     ctx->attr_mask |= GGD_ATTR_TILEBIN;
   }
-  hipLaunchKernelGGL(tilebin_count_kernel, dim3(nb), dim3(TB_THREADS), lds_count, s, prm.width, prm.height, splat,
+  hipLaunchKernelGGL(tilebin_count_kernel, dim3(nb), dim3(TB_THREADS), lds_count, s, prm.width, prm.height, rect,
                      tiles_touched, order, n_vis_ptr, prm.P, counts, T);
   hipLaunchKernelGGL(tilebin_scan_kernel, dim3((T + 63) / 64), dim3(64 * TS_WAVES), 0, s, counts, T, n_vis_ptr, prm.P, totals);
-  hipLaunchKernelGGL(tilebin_scatter_kernel, dim3(nb), dim3(TB_THREADS), lds_scatter, s, prm.width, prm.height, splat,
+  hipLaunchKernelGGL(tilebin_scatter_kernel, dim3(nb), dim3(TB_THREADS), lds_scatter, s, prm.width, prm.height, rect,
                      tiles_touched, order, n_vis_ptr, prm.P, counts, totals, T, tbits, list, ranges, capacity);
   GGD_HIP(hipGetLastError());
   return GGD_OK;

@@ -69,15 +69,18 @@ typedef struct ggd_params {
   int32_t reserved_;
 } ggd_params;
 
-/* One record per Gaussian, written by the preprocess kernel and gathered by the blend kernels. */
+/* One record per Gaussian, written by the preprocess kernel and gathered by the blend kernels: exactly what a blended
+ * (tile, Gaussian) instance needs, with the per-Gaussian constants of the inner loop formed ONCE here instead of once
+ * per instance: the three coefficients of  power = fma(fma(hA, dx, nB*dy), dx, (hC*dy)*dy)  (hA = -A/2, nB = -B,
+ * hC = -C/2 are exact rescalings of the conic (A, B, C): A = -2 hA etc. bit for bit), the power-domain cull threshold
+ * and the half extents of the axis-aligned box outside of which alpha < 1/255 for sure. */
 typedef struct ggd_splat {
   float x, y;               /* pixel-space centre ("means2D" upstream) */
-  float conA, conB, conC;   /* inverse 2D covariance (conic) */
+  float hA, nB, hC;         /* -conic.A / 2, -conic.B, -conic.C / 2 (conic = inverse 2D covariance) */
+  float thr;                /* ln(1 / (255 opacity)) lowered by a safety margin: power < thr  =>  alpha < 1/255 */
   float opacity;
   float r, g, b;            /* colour after SH evaluation / colors_precomp */
-  float depth;              /* view-space z; its raw bits are the low half of the sort key */
-  int32_t radius;           /* == radii[i] */
-  uint32_t tiles_touched;
+  float ex, ey;             /* half extents of the box {power >= thr}, inflated for fp32 rounding (+inf: keep always) */
 } ggd_splat;                /* 48 bytes */
 
 /* Byte offsets of the named arrays inside the caller-owned buffers (for tests / debug taps / bindings). */
@@ -87,6 +90,7 @@ typedef struct ggd_geom_view {
   size_t point_offsets; /* uint32[P], inclusive prefix sum of tiles_touched */
   size_t clamped;       /* uint8[P], bit c set <=> colour channel c was clamped at 0 */
   size_t depth_keys;    /* uint32[P]: raw fp32 bits of the view-space depth, 0xFFFFFFFF for culled Gaussians */
+  size_t rect;          /* uint32[2*P]: tile rect {minx | maxx << 16, miny | maxy << 16}, zero for culled Gaussians */
   size_t header;        /* uint32[64]: reserved (zeroed) */
   size_t total;
 } ggd_geom_view;
@@ -198,8 +202,8 @@ enum {
                              1 (default) = auto: 3 when num_rendered >= 3*2^18 (2 on larger grids, from 2^20), else 0.
                              debug=1 (key taps) or a tile grid beyond the LDS budget always uses 0 */
   GGD_OPT_BLEND_SPLIT = 3, /* blend kernels: 0 = one wave per 16x16 tile (4 px/lane), 2 = two waves per tile (16x8
-                             halves, 2 px/lane), 1 (default) = auto (forward: two; backward: two below 4096 tiles,
-                             where one wave per tile cannot fill the 1024 SIMDs).  Forward results are identical; backward
+                             halves, 2 px/lane), 3 = four waves per tile (8x8 quarters, 1 px/lane), 1 (default) = auto
+                             (the measured best per kernel).  Forward results are identical; backward
                              sums differ only in their fp32 summation order. */
   GGD_OPT_COUNT
 };

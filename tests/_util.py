@@ -111,11 +111,16 @@ def decode_buffers(P, W, H, R, geom, binning, img):
     gv, bv, iv = _capi.geom_view(P), _capi.binning_view(R), _capi.img_view(W, H)
     g = geom.cpu().numpy(); b = binning.cpu().numpy(); im = img.cpu().numpy()
     T = ((W + 15) // 16) * ((H + 15) // 16)
-    splat = g[gv.splat:gv.splat + 48 * P].view(np.float32).reshape(P, 12)
+    splat = g[gv.splat:gv.splat + 48 * P].view(np.float32).reshape(P, 12)   # x y hA nB hC thr opacity r g b ex ey
+    dk = g[gv.depth_keys:gv.depth_keys + 4 * P].view(np.uint32)
+    rect = g[gv.rect:gv.rect + 8 * P].view(np.uint32).reshape(P, 2)
     out = dict(
-        xy=splat[:, 0:2], conic_opacity=np.stack([splat[:, 2], splat[:, 3], splat[:, 4], splat[:, 5]], 1),
-        rgb=splat[:, 6:9], depths=splat[:, 9], splat_radius=splat[:, 10].view(np.int32),
-        splat_tiles=splat[:, 11].view(np.uint32),
+        xy=splat[:, 0:2],
+        # conic (A, B, C) = (-2 hA, -nB, -2 hC): exact rescalings, so bit-comparable with the oracle's conic
+        conic_opacity=np.stack([np.float32(-2.0) * splat[:, 2], -splat[:, 3], np.float32(-2.0) * splat[:, 4], splat[:, 6]], 1),
+        rgb=splat[:, 7:10], power_threshold=splat[:, 5], cull_extent=splat[:, 10:12],
+        depths=np.where(dk == 0xFFFFFFFF, np.uint32(0), dk).view(np.float32),
+        rect=np.stack([rect[:, 0] & 0xffff, rect[:, 1] & 0xffff, rect[:, 0] >> 16, rect[:, 1] >> 16], 1).astype(np.int32),
         tiles_touched=g[gv.tiles_touched:gv.tiles_touched + 4 * P].view(np.uint32),
         point_offsets=g[gv.point_offsets:gv.point_offsets + 4 * P].view(np.uint32),
         clamped=g[gv.clamped:gv.clamped + P],

@@ -48,8 +48,9 @@ def test_forward_stages_match_oracle(native_lib, case):
     np.testing.assert_array_equal(n["point_offsets"], o["point_offsets"])
     assert n["num_rendered"] == o["num_rendered"]
     # ---- float outputs of the per-Gaussian stage: same op order, no contraction -> bit-exact
-    for name in ("depths", "xy", "conic_opacity", "rgb"):
+    for name in ("depths", "xy", "conic_opacity", "rgb", "rect"):
         np.testing.assert_array_equal(n[name][vis], o[name][vis], err_msg=name)
+    assert (n["rect"][~vis] == 0).all()
     if d["shs"] is not None:
         packed = (o["clamped"] * np.array([1, 2, 4], np.uint8)).sum(1).astype(np.uint8)
         np.testing.assert_array_equal(n["clamped"][vis], packed[vis])
@@ -128,7 +129,7 @@ def test_single_call_forward_capacity_overflow_is_retried(native_lib, path):
 
 
 def test_blend_options_do_not_change_the_image(native_lib):
-    """Wave-level culling (GGD_OPT_BLEND_CULL) and the two-waves-per-tile split (GGD_OPT_BLEND_SPLIT) are exact
+    """Wave-level culling (GGD_OPT_BLEND_CULL) and the waves-per-tile split (GGD_OPT_BLEND_SPLIT) are exact
     optimisations: image, final_T and n_contrib are bit-identical with them on or off.  The exp variants
     (GGD_OPT_EXP_MODE 0/1/2) may differ by ulps only: <= 1e-5 against each other."""
     from gaussian_gan_decoder_amd import _capi
@@ -138,7 +139,7 @@ def test_blend_options_do_not_change_the_image(native_lib):
     try:
         base = run_native(d, debug=False)
         for cull in (0, 1):
-            for split in (0, 1):
+            for split in (0, 1, 2, 3):   # one / auto / two (16x8) / four (8x8) waves per tile
                 cx.set_option(_capi.OPT_BLEND_CULL, cull); cx.set_option(_capi.OPT_BLEND_SPLIT, split)
                 n = run_native(d, debug=False)
                 np.testing.assert_array_equal(n["color"].cpu().numpy(), base["color"].cpu().numpy())
