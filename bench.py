@@ -111,6 +111,46 @@ def cpu_baseline(P, S, kind):
             "host_cores": ncores}
 
 
+def tile_list_stats(img, W, H):
+    """Mean / max length of the per-tile Gaussian lists of one rendered frame (from the `ranges` array of the image
+    buffer the forward returned): SURVEY.md 8d asks for them next to every number."""
+    from gaussian_gan_decoder_amd import _capi
+    iv = _capi.img_view(W, H)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    rg = img[iv.ranges:iv.ranges + 8 * T].view(torch.int32).reshape(T, 2).to(torch.int64)
+    ln = (rg[:, 1] - rg[:, 0])
+    return {"mean": float(ln.float().mean().item()), "max": int(ln.max().item()), "tiles": T}
+
+
+def pmc_moved_bytes(workload):
+    """Sum of the measured HBM bytes (committed PMC passes, see pmc_traffic) of every forward kernel of one frame."""
+    import glob
+    best = None
+    for fn in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "traffic.json"))):
+        try:
+            doc = json.load(open(fn))
+        except (OSError, ValueError):
+            continue
+        if doc.get("workload") != workload or "forward_kernels" not in doc:
+            continue
+        best = {"bytes": sum(doc["kernels"][k]["hbm_bytes"] * doc["forward_kernels"][k] for k in doc["forward_kernels"]
+                             if k in doc["kernels"]), "source": os.path.relpath(fn, os.path.dirname(os.path.abspath(__file__)))}
+    return best
+
+
+def pmc_mlp(profile_key="decoder_forward_kernel"):
+    """MFMA evidence for the fused decoder MLP from the committed rocprofv3 passes (profiles/*/mlp_pmc.json)."""
+    import glob
+    best = None
+    for fn in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "mlp_pmc.json"))):
+        try:
+            best = json.load(open(fn))
+            best["source"] = os.path.relpath(fn, os.path.dirname(os.path.abspath(__file__)))
+        except (OSError, ValueError):
+            continue
+    return best
+
+
 def pmc_valu(workload, stage):
     """SQ_INSTS_VALU per launch of the stage's kernel from the same committed PMC pass (see pmc_traffic)."""
     import glob
@@ -221,6 +261,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     num_rendered = out[0]
+    tile_lists = tile_list_stats(out[5], S, S)
 
     # ---- per-frame device time distribution (hipEvent pairs on the launch stream; SURVEY 8d: median and p10 / p90)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(100, max(20, args.steps)))]
@@ -246,7 +287,7 @@ def main():
         # the other synthetic configurations of BASELINE.json's north_star ({100k, 1M} x {512, 1024}), forward raster only,
         # 100 frames each -- reported for the table in DESIGN.md; the headline `value` is the workload above
         sweep = {}
-        for name in ("100k_512_cube", "100k_1024_cube", "1M_512_cube"):
+        for name in ("1M_1024_shell", "100k_512_cube", "100k_1024_cube", "1M_512_cube"):
             if name == args.workload:
                 continue
             P2, S2, kind2 = WORKLOADS[name]
@@ -265,7 +306,8 @@ def main():
                     o2 = R.rasterize_gaussians_native(*a2)
                 torch.cuda.synchronize(dev)
                 batches.append((time.perf_counter() - t2) / 20)
-            sweep[name] = {"frames_per_s": 1.0 / sorted(batches)[2], "num_rendered": int(o2[0])}
+            sweep[name] = {"frames_per_s": 1.0 / sorted(batches)[2], "num_rendered": int(o2[0]),
+                           "tile_list_length": tile_list_stats(o2[5], S2, S2)}
             del sc2, a2, o2
         extra["forward_fps_other_workloads"] = sweep
     if args.backward:
@@ -414,7 +456,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{P} synthetic Gaussians ('{kind}' scene, seed 0, SH degree 0), {S}x{S}, forward "
                                "raster fp32, inputs resident in HBM", "num_rendered": num_rendered,
-                   "tiles": ((S + 15) // 16) ** 2, "parallelism": f"scene-parallel x{world} (no collective)"},
+                   "tiles": ((S + 15) // 16) ** 2, "tile_list_length_mean": tile_lists["mean"],
+                   "tile_list_length_max": tile_lists["max"], "parallelism": f"scene-parallel x{world} (no collective)"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, dom),
                      "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": stage_ms[dom],
@@ -424,10 +467,23 @@ def main():
                          pmc_valu(args.workload, dom))},
         "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
         "frame_ms_percentiles": {k: (round(v, 5) if k != "n" else v) for k, v in frame_pct.items()},
+        # SURVEY 8d's formula prices the reference's 6-pass 64-bit radix sort; the production path (depth sort of P keys +
+        # two binning passes) moves far fewer bytes -- the measured (PMC) figure is printed beside the contract's
         "whole_frame": {"algorithmic_bytes": whole, "GBps": whole / (ms_per_step * 1e-3) / 1e9,
                         "frac_of_hbm_peak": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
+    moved = pmc_moved_bytes(args.workload)
+    if moved is not None:
+        result["whole_frame"].update({"moved_bytes_pmc": moved["bytes"], "moved_GBps": moved["bytes"] / (ms_per_step * 1e-3) / 1e9,
+                                      "moved_frac_of_hbm_peak": moved["bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "moved_bytes_source": moved["source"]})
     if decode is not None:
+        m = pmc_mlp()
+        if m is not None:   # MFMA-side roofline entry for the fused decoder MLP (committed rocprofv3 passes)
+            decode["roofline"] = {"bound": "mfma", "achieved": decode["mlp_TFLOPs"], "peak": 2500.0, "unit": "TFLOP/s",
+                                  "frac": decode["mlp_frac_of_bf16_dense_peak"], "mfma_busy": m.get("mfma_busy_frac"),
+                                  "valu_insts": m.get("valu_insts"), "kernel_us_rocprof": m.get("kernel_us"),
+                                  "source": m.get("source")}
         result["decode_render"] = decode
     if train is not None:
         result["train"] = train

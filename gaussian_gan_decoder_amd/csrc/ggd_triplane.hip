@@ -69,6 +69,77 @@ __global__ __launch_bounds__(256) void triplane_kernel(const float* __restrict__
   if (!BACKWARD) out[n * C + c] = acc * (1.0f / 3.0f);
 }
 
+// ---- PanoHead tri-grid: every "plane" is a C x D grid sampled with a 3-D grid_sample (trilinear, zero padding,
+// align_corners = False) at the point's three projected coordinates (PanoHead/training/volumetric_rendering/
+// renderer.py:47-58; selected at main/decoder_models/sequential_decoder_reverse.py:42-50).  (u, v, w) index (W, H, D).
+// axes: 0 = EG3D plane axes (plane 2 -> (z, x, y)), 1 = PanoHead (plane 2 -> (y, z, x)); plane 0 -> (x, y, z),
+// plane 1 -> (x, z, y) in both.  Grids are channel-last [3][D][H][W][C]: lane = channel, one coalesced line per texel.
+__device__ __forceinline__ void grid_uvw(int axes, int p, float x, float y, float z, float& u, float& v, float& w) {
+  if (p == 0) { u = x; v = y; w = z; }
+  else if (p == 1) { u = x; v = z; w = y; }
+  else if (axes == 0) { u = z; v = x; w = y; }
+  else { u = y; v = z; w = x; }
+}
+
+template <int C, bool BACKWARD>
+__global__ __launch_bounds__(256) void trigrid_kernel(const float* __restrict__ grids_cl, float* __restrict__ dgrids_cl,
+                                                      int D, int H, int W, int axes, const float* __restrict__ pos, int N,
+                                                      float scale, const float* __restrict__ dout, float* __restrict__ out) {
+  constexpr int PPW = 64 / C;  // points per wave
+  const int lane = threadIdx.x & 63;
+  const int c = lane % C;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t n = wave * PPW + lane / C;
+  if (n >= N) return;
+  const float x = scale * pos[3 * n], y = scale * pos[3 * n + 1], z = scale * pos[3 * n + 2];
+  const size_t grid_stride = (size_t)D * H * W * C;
+  float acc = 0.0f;
+  const float g = BACKWARD ? dout[n * C + c] * (1.0f / 3.0f) : 0.0f;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    float u, v, w;
+    grid_uvw(axes, p, x, y, z, u, v, w);
+    const float ix = ((u + 1.0f) * (float)W - 1.0f) * 0.5f;
+    const float iy = ((v + 1.0f) * (float)H - 1.0f) * 0.5f;
+    const float iz = ((w + 1.0f) * (float)D - 1.0f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float ax = ix - fx, ay = iy - fy, az = iz - fz;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int xx = x0 + (k & 1), yy = y0 + ((k >> 1) & 1), zz = z0 + (k >> 2);
+      if (xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D) {
+        // weights in grid_sampler_3d's order: (x) * (y) * (z)
+        const float wgt = ((k & 1) ? ax : 1.0f - ax) * ((k & 2) ? ay : 1.0f - ay) * ((k & 4) ? az : 1.0f - az);
+        const size_t off = p * grid_stride + (((size_t)zz * H + yy) * W + xx) * C + c;
+        if (BACKWARD) atomicAdd(dgrids_cl + off, wgt * g);
+        else acc += wgt * grids_cl[off];
+      }
+    }
+  }
+  if (!BACKWARD) out[n * C + c] = acc * (1.0f / 3.0f);
+}
+
+template <bool BACKWARD>
+int launch_trigrid(ggd_ctx* ctx, hipStream_t s, const float* grids_cl, float* dgrids_cl, int C, int D, int H, int W, int axes,
+                   const float* pos, int N, float box_warp, const float* dout, float* out) {
+  if (N <= 0) return GGD_OK;
+  const float scale = 2.0f / box_warp;
+#define GGD_TG(CC)                                                                                                  \
+  case CC: {                                                                                                        \
+    const int64_t waves = ((int64_t)N + (64 / CC) - 1) / (64 / CC);                                                 \
+    hipLaunchKernelGGL((trigrid_kernel<CC, BACKWARD>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s,          \
+                       grids_cl, dgrids_cl, D, H, W, axes, pos, N, scale, dout, out);                               \
+  } break;
+  switch (C) {
+    GGD_TG(1) GGD_TG(2) GGD_TG(4) GGD_TG(8) GGD_TG(16) GGD_TG(32) GGD_TG(64)
+    default: return ggd_fail(ctx, GGD_E_INVALID, "trigrid: channel count must be a power of two <= 64");
+  }
+#undef GGD_TG
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
 template <bool BACKWARD>
 int launch(ggd_ctx* ctx, hipStream_t s, const float* planes_cl, float* dplanes_cl, int C, int H, int W, const float* pos,
            int N, float box_warp, const float* dout, float* out) {
@@ -338,4 +409,25 @@ extern "C" int ggd_triplane_backward(ggd_ctx* ctx, void* stream, int32_t C, int3
                    : launch_binned_backward<16>(ctx, s, H, W, pos, N, box_warp, dout, dplanes_cl, ctx->scratch);
   }
   return launch<true>(ctx, s, nullptr, dplanes_cl, C, H, W, pos, N, box_warp, dout, nullptr);
+}
+
+extern "C" int ggd_trigrid_forward(ggd_ctx* ctx, void* stream, const float* grids_cl, int32_t C, int32_t D, int32_t H,
+                                   int32_t W, int32_t axes, const float* pos, int32_t N, float box_warp, float* out) {
+  if (!ctx) return GGD_E_INVALID;
+  if (axes < 0 || axes > 1 || D <= 0) return ggd_fail(ctx, GGD_E_INVALID, "ggd_trigrid_forward: bad axes / depth");
+  if (N > 0 && (!grids_cl || !pos || !out || H <= 0 || W <= 0 || box_warp == 0.0f))
+    return ggd_fail(ctx, GGD_E_INVALID, "ggd_trigrid_forward: bad argument");
+  return launch_trigrid<false>(ctx, static_cast<hipStream_t>(stream), grids_cl, nullptr, C, D, H, W, axes, pos, N, box_warp,
+                               nullptr, out);
+}
+
+extern "C" int ggd_trigrid_backward(ggd_ctx* ctx, void* stream, int32_t C, int32_t D, int32_t H, int32_t W, int32_t axes,
+                                    const float* pos, int32_t N, float box_warp, const float* dout, float* dgrids_cl) {
+  if (!ctx) return GGD_E_INVALID;
+  if (!dgrids_cl || H <= 0 || W <= 0 || C <= 0 || D <= 0 || axes < 0 || axes > 1)
+    return ggd_fail(ctx, GGD_E_INVALID, "ggd_trigrid_backward: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  GGD_HIP(hipMemsetAsync(dgrids_cl, 0, (size_t)3 * D * H * W * C * sizeof(float), s));
+  if (N > 0 && (!pos || !dout || box_warp == 0.0f)) return ggd_fail(ctx, GGD_E_INVALID, "ggd_trigrid_backward: bad argument");
+  return launch_trigrid<true>(ctx, s, nullptr, dgrids_cl, C, D, H, W, axes, pos, N, box_warp, dout, nullptr);
 }

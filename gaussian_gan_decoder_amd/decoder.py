@@ -6,8 +6,10 @@ averaged) and main/decoder_models/sequential_decoder_reverse.py:27-36,61-86 (`Se
 colour -> opacity -> rotation -> scale -> xyz heads, scale activation -softplus(s+5)-2.5, xyz = head*0.01 + position)
 with the same parameter names (`color_decoder.backbone.0.weight`, ...), so a reference state_dict loads unchanged.
 The frozen/finetuned GAN that produces the feature planes (PanoHead / EG3D TriPlaneGenerator) is out of scope; the
-decoder here consumes a feature-plane tensor directly ([3, C, H, W], the EG3D layout of
-eg3d/training/volumetric_rendering/renderer.py:23-65).
+decoder here consumes a feature-plane tensor directly: [3, C, H, W] tri-planes (EG3D,
+eg3d/training/volumetric_rendering/renderer.py:23-65) or [3, C * D, H, W] tri-grids (PanoHead,
+PanoHead/training/volumetric_rendering/renderer.py:47-58); tests/golden/panohead_fixture.npz pins the PanoHead form
+against the reference's own generator + decoder run end to end on one seeded z.
 """
 from __future__ import annotations
 
@@ -16,23 +18,83 @@ from types import SimpleNamespace
 import torch
 from torch import nn
 
-# plane axes of eg3d/training/volumetric_rendering/renderer.py:23-38
-_PLANE_AXES = torch.tensor([[[1, 0, 0], [0, 1, 0], [0, 0, 1]],
-                            [[1, 0, 0], [0, 0, 1], [0, 1, 0]],
-                            [[0, 0, 1], [1, 0, 0], [0, 1, 0]]], dtype=torch.float32)
+# plane axes: eg3d/training/volumetric_rendering/renderer.py:23-38 and PanoHead/training/volumetric_rendering/renderer.py
+# (generate_planes): they differ in the third plane -- EG3D projects it to (z, x), PanoHead to (y, z)
+PLANE_AXES = {
+    "eg3d": torch.tensor([[[1, 0, 0], [0, 1, 0], [0, 0, 1]],
+                          [[1, 0, 0], [0, 0, 1], [0, 1, 0]],
+                          [[0, 0, 1], [1, 0, 0], [0, 1, 0]]], dtype=torch.float32),
+    "panohead": torch.tensor([[[1, 0, 0], [0, 1, 0], [0, 0, 1]],
+                              [[1, 0, 0], [0, 0, 1], [0, 1, 0]],
+                              [[0, 1, 0], [0, 0, 1], [1, 0, 0]]], dtype=torch.float32),
+}
+_PLANE_AXES = PLANE_AXES["eg3d"]
 
 
-def sample_from_planes(plane_features: torch.Tensor, coordinates: torch.Tensor, box_warp: float = 1.0) -> torch.Tensor:
-    """plane_features [3, C, H, W], coordinates [M, 3] in [-box_warp/2, box_warp/2] -> [3, M, C]
-    (bilinear, zero padding, align_corners=False; same projection as renderer.py:40-65)."""
-    n_planes, C, H, W = plane_features.shape
+def sample_from_planes(plane_features: torch.Tensor, coordinates: torch.Tensor, box_warp: float = 1.0,
+                       plane_axes: str = "eg3d", triplane_depth=None) -> torch.Tensor:
+    """plane_features [3, C, H, W] (EG3D) or [3, C * D, H, W] with triplane_depth = D (PanoHead tri-grid),
+    coordinates [M, 3] in [-box_warp/2, box_warp/2] -> [3, M, C]; bilinear / trilinear, zero padding,
+    align_corners=False.  triplane_depth=None: the 2-D form of eg3d/.../renderer.py:40-65; an integer: the 3-D
+    grid_sample of PanoHead/training/volumetric_rendering/renderer.py:47-58 over the C x D grid, all three projected
+    coordinates used (also for D = 1, where the depth coordinate attenuates the sample as it does in the reference)."""
+    n_planes = plane_features.shape[0]
     M = coordinates.shape[0]
     coords = (2.0 / box_warp) * coordinates
-    inv = torch.linalg.inv(_PLANE_AXES.to(coords.device, coords.dtype))          # [3,3,3]
-    proj = torch.einsum("mc,pcd->pmd", coords, inv)[..., :2]                        # [3, M, 2]
-    out = torch.nn.functional.grid_sample(plane_features, proj.unsqueeze(1).float(), mode="bilinear",
-                                          padding_mode="zeros", align_corners=False)  # [3, C, 1, M]
-    return out.permute(0, 3, 2, 1).reshape(n_planes, M, C)
+    inv = torch.linalg.inv(PLANE_AXES[plane_axes].to(coords.device, coords.dtype))   # [3,3,3]
+    proj = torch.einsum("mc,pcd->pmd", coords, inv)                                    # [3, M, 3]
+    if triplane_depth is None:
+        out = torch.nn.functional.grid_sample(plane_features, proj[..., :2].unsqueeze(1).float(), mode="bilinear",
+                                              padding_mode="zeros", align_corners=False)  # [3, C, 1, M]
+        return out.permute(0, 3, 2, 1).reshape(n_planes, M, -1)
+    D = int(triplane_depth)
+    _, CD, H, W = plane_features.shape
+    C = CD // D
+    grid5 = plane_features.view(n_planes, C, D, H, W)
+    out = torch.nn.functional.grid_sample(grid5, proj.unsqueeze(1).unsqueeze(2).float(), mode="bilinear",
+                                          padding_mode="zeros", align_corners=False)       # [3, C, 1, 1, M]
+    return out.permute(0, 4, 3, 2, 1).reshape(n_planes, M, C)
+
+
+class _TrigridMeanFn(torch.autograd.Function):
+    """mean over the 3 planes of the tri-grid sample_from_planes, through the HIP gather kernel (csrc/ggd_triplane.hip,
+    ggd_trigrid_*): grids are handed over channel-last [3][D][H][W][C]."""
+
+    @staticmethod
+    def forward(ctx, plane_features, coordinates, box_warp, axes_mode, depth):
+        import ctypes as C
+        from . import _capi
+        dev = plane_features.device
+        n_planes, CD, H, W = plane_features.shape
+        Cc = CD // depth
+        grids_cl = plane_features.view(n_planes, Cc, depth, H, W).permute(0, 2, 3, 4, 1).contiguous().float()
+        pos = coordinates.contiguous().float()
+        out = torch.empty((pos.shape[0], Cc), dtype=torch.float32, device=dev)
+        cx = _capi.context_for(dev)
+        with torch.cuda.device(dev):
+            cx.check(cx.lib.ggd_trigrid_forward(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
+                                                C.c_void_p(grids_cl.data_ptr()), Cc, depth, H, W, axes_mode,
+                                                C.c_void_p(pos.data_ptr()), pos.shape[0], float(box_warp),
+                                                C.c_void_p(out.data_ptr())))
+        ctx.save_for_backward(pos)
+        ctx.meta = (Cc, depth, H, W, float(box_warp), axes_mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes as C
+        from . import _capi
+        (pos,) = ctx.saved_tensors
+        Cc, depth, H, W, box_warp, axes_mode = ctx.meta
+        dev = pos.device
+        dout = dout.contiguous().float()
+        dgrids_cl = torch.empty((3, depth, H, W, Cc), dtype=torch.float32, device=dev)
+        cx = _capi.context_for(dev)
+        with torch.cuda.device(dev):
+            cx.check(cx.lib.ggd_trigrid_backward(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), Cc, depth,
+                                                 H, W, axes_mode, C.c_void_p(pos.data_ptr()), pos.shape[0], box_warp,
+                                                 C.c_void_p(dout.data_ptr()), C.c_void_p(dgrids_cl.data_ptr())))
+        return dgrids_cl.permute(0, 4, 1, 2, 3).reshape(3, Cc * depth, H, W), None, None, None, None
 
 
 class _TriplaneMeanFn(torch.autograd.Function):
@@ -73,14 +135,19 @@ class _TriplaneMeanFn(torch.autograd.Function):
         return dplanes_cl.permute(0, 3, 1, 2), None, None
 
 
-def triplane_mean(plane_features: torch.Tensor, coordinates: torch.Tensor, box_warp: float = 1.0) -> torch.Tensor:
-    """== sample_from_planes(...).mean(0): [3, C, H, W], [M, 3] -> [M, C].  HIP gather kernel on the GPU (C a power of
-    two <= 64, 3 planes); the torch ops on the CPU (the decoder is host-side PyTorch per the north_star, so a CPU
-    path exists for tests -- unlike the rasterizer)."""
-    C = plane_features.shape[1]
-    if plane_features.is_cuda and plane_features.shape[0] == 3 and C <= 64 and (C & (C - 1)) == 0:
+def triplane_mean(plane_features: torch.Tensor, coordinates: torch.Tensor, box_warp: float = 1.0,
+                  plane_axes: str = "eg3d", triplane_depth=None) -> torch.Tensor:
+    """== sample_from_planes(...).mean(0): [3, C(*D), H, W], [M, 3] -> [M, C].  HIP gather kernels on the GPU (C a power
+    of two <= 64, 3 planes; 2-D EG3D form or the PanoHead tri-grid); the torch ops on the CPU (the decoder is host-side
+    PyTorch per the north_star, so a CPU path exists for tests -- unlike the rasterizer)."""
+    C = plane_features.shape[1] // (1 if triplane_depth is None else int(triplane_depth))
+    ok = plane_features.is_cuda and plane_features.shape[0] == 3 and C <= 64 and (C & (C - 1)) == 0
+    if ok and triplane_depth is None and plane_axes == "eg3d":
         return _TriplaneMeanFn.apply(plane_features, coordinates, box_warp)
-    return sample_from_planes(plane_features, coordinates, box_warp).mean(0)
+    if ok and triplane_depth is not None:
+        return _TrigridMeanFn.apply(plane_features, coordinates, box_warp, {"eg3d": 0, "panohead": 1}[plane_axes],
+                                    int(triplane_depth))
+    return sample_from_planes(plane_features, coordinates, box_warp, plane_axes, triplane_depth).mean(0)
 
 
 class _TallLinearFn(torch.autograd.Function):
@@ -139,10 +206,19 @@ class Decoder(nn.Module):
 class SequentialDecoderReverse(nn.Module):
     """Feature planes + positions -> raw Gaussian attributes (xyz, scale, rotation, opacity, color)."""
 
-    def __init__(self, plane_channels=32, hidden_dim=128, position_dim=3, box_warp=1.0):
+    def __init__(self, plane_channels=32, hidden_dim=128, position_dim=3, box_warp=1.0, plane_axes="eg3d",
+                 triplane_depth=None):
+        """plane_axes / triplane_depth: which generator produced the planes -- "eg3d", None: EG3D tri-planes [3, 32, H, W];
+        "panohead", D: PanoHead tri-grids [3, 32 * D, H, W] (G.rendering_kwargs["triplane_depth"],
+        sequential_decoder_reverse.py:42-50).  position_dim must be 3: the reference's optional positional encoding
+        (use_xyz_embedding, default off in main/train_pano2gaussian_decoder.py:46) is not implemented."""
         super().__init__()
+        if position_dim != 3:
+            raise NotImplementedError("positional encoding of the positions (use_xyz_embedding) is not implemented")
         f = plane_channels + position_dim
         self.box_warp = box_warp
+        self.plane_axes = plane_axes
+        self.triplane_depth = triplane_depth
         self.color_decoder = Decoder(f, 3, hidden_dim)
         self.opacity_decoder = Decoder(f + 3, 1, hidden_dim)
         self.rotation_decoder = Decoder(f + 4, 4, hidden_dim)
@@ -154,7 +230,8 @@ class SequentialDecoderReverse(nn.Module):
         return -self.scale_activation(scale + 5) - 2.5
 
     def forward(self, feature_planes, init_position):
-        pf = triplane_mean(feature_planes, init_position, self.box_warp)  # the 5 heads all average the planes
+        # the 5 heads all average the three planes' samples
+        pf = triplane_mean(feature_planes, init_position, self.box_warp, self.plane_axes, self.triplane_depth)
         info = init_position
         color = self.color_decoder(pf, info)
         info = torch.concat([info, color], dim=-1)

@@ -230,14 +230,16 @@ class FusedTrainDecoder(torch.nn.Module):
         """Several scenes (own feature planes, positions[B,N,3]) through ONE decoder launch: attrs[B,N,16].  The
         weight gradients are then formed once per step instead of once per scene."""
         B, N = positions.shape[0], positions.shape[1]
-        feats = torch.cat([triplane_mean(planes_list[b], positions[b], self.decoder.box_warp) for b in range(B)], dim=0)
+        feats = torch.cat([triplane_mean(planes_list[b], positions[b], self.decoder.box_warp, self.decoder.plane_axes,
+                                         self.decoder.triplane_depth) for b in range(B)], dim=0)
         params = [t for head in _head_tensors(self.decoder) for t in head]
         packed, packed_t = self._images(params)
         a = FusedDecoderFn.apply(feats, positions.reshape(B * N, 3), packed, packed_t, *params)
         return a.view(B, N, 16)
 
     def forward(self, feature_planes, init_position):
-        feats = triplane_mean(feature_planes, init_position, self.decoder.box_warp)
+        feats = triplane_mean(feature_planes, init_position, self.decoder.box_warp, self.decoder.plane_axes,
+                              self.decoder.triplane_depth)
         params = [t for head in _head_tensors(self.decoder) for t in head]
         packed, packed_t = self._images(params)
         a = FusedDecoderFn.apply(feats, init_position, packed, packed_t, *params)
@@ -248,6 +250,7 @@ class FusedDecoder:
     def __init__(self, decoder: SequentialDecoderReverse):
         self.decoder = decoder
         self.box_warp = decoder.box_warp
+        self.plane_axes, self.triplane_depth = decoder.plane_axes, decoder.triplane_depth
         self.repack()
 
     def repack(self):
@@ -272,6 +275,6 @@ class FusedDecoder:
 
     @torch.no_grad()
     def __call__(self, feature_planes: torch.Tensor, init_position: torch.Tensor) -> SimpleNamespace:
-        feats = triplane_mean(feature_planes, init_position, self.box_warp)
+        feats = triplane_mean(feature_planes, init_position, self.box_warp, self.plane_axes, self.triplane_depth)
         a = self.decode_features(feats, init_position)
         return SimpleNamespace(color=a[:, 0:3], opacity=a[:, 3:4], rotation=a[:, 4:8], scale=a[:, 8:11], xyz=a[:, 11:14])

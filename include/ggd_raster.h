@@ -227,6 +227,18 @@ int ggd_triplane_backward(ggd_ctx* ctx, void* stream, int32_t C, int32_t H, int3
                           float box_warp, const float* dout, float* dplanes_cl);
 
 /*
+ * The PanoHead form of the same gather: every plane is a C x D "tri-grid" sampled with a 3-D grid_sample (trilinear,
+ * zero padding, align_corners = False) at all three projected coordinates (PanoHead/training/volumetric_rendering/
+ * renderer.py:47-58, chosen at sequential_decoder_reverse.py:42-50 when the generator has `triplane_depth`).
+ * grids_cl is CHANNEL-LAST [3][D][H][W][C]; axes: 0 = EG3D plane axes, 1 = PanoHead plane axes (they differ in the third
+ * plane).  out[n,:] = mean over the 3 grids.  The backward zero-fills dgrids_cl and scatter-adds dout[N,C].
+ */
+int ggd_trigrid_forward(ggd_ctx* ctx, void* stream, const float* grids_cl, int32_t C, int32_t D, int32_t H, int32_t W,
+                        int32_t axes, const float* pos, int32_t N, float box_warp, float* out);
+int ggd_trigrid_backward(ggd_ctx* ctx, void* stream, int32_t C, int32_t D, int32_t H, int32_t W, int32_t axes,
+                         const float* pos, int32_t N, float box_warp, const float* dout, float* dgrids_cl);
+
+/*
  * Fused per-point decoder, inference (bf16 MFMA, fp32 accumulate): the 5 chained `Decoder` MLPs of
  * main/decoder_models/sequential_decoder_reverse.py:68-85 in ONE launch.
  *   feat  [N,32]  mean-of-planes features (ggd_triplane_forward)      pos [N,3] positions
