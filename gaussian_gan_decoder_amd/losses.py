@@ -1,81 +1,22 @@
 """Image losses of the decoder training step (main/train_pano2gaussian_decoder.py:246-261).
 
-PyTorch re-statements (device-agnostic, same signatures and return values as the reference):
-  l1_loss, l2_loss, ssim      gaussian_splatting/utils/loss_utils.py:17-63
-  sobel_loss                  main/loss_utils/sobel_loss.py:19-30  (the reference builds its kernels on "cuda" at import)
-and `fused_image_loss`: all four terms and d(loss)/d(image) in three HIP launches (csrc/ggd_imgloss.hip), as one
-autograd node.  The perceptual / identity terms of the reference need external networks (VGG, ArcFace) and are out of
-scope.
+`fused_image_loss`: L1, L2, 1 - SSIM and the Sobel term (gaussian_splatting/utils/loss_utils.py:17-63,
+main/loss_utils/sobel_loss.py:19-30) and d(loss)/d(image) in three HIP launches (csrc/ggd_imgloss.hip), as one autograd
+node; pinned by vectors from the reference's own functions (tests/golden/losses.npz).  The PyTorch evaluation of the
+same terms lives under tests/ (the checker).
+`PerceptualStandIn`: the slot of the reference's LPIPS term (main/loss_utils/lpips.py:6-34: VGG16 features of the image
+and the target at 256 x 256, squared distance).  The pretrained VGG is an external download and out of scope; the
+stand-in is a FIXED, seeded, random-initialised network of the same shape (VGG16's 13 3x3 convolutions, taps after
+conv1_2 / 2_2 / 3_3 / 4_3 / 5_3, channel-normalised, per-channel weights), so that the training step carries the same
+amount of convolution work and the same kind of gradient path into the rendered image.  It runs in PyTorch-ROCm (MIOpen)
+like the reference's own VGG.  The identity term needs ArcFace and stays out.
 """
 from __future__ import annotations
 
 import ctypes as C
-from math import exp
 
 import torch
 import torch.nn.functional as F
-
-
-def l1_loss(network_output, gt):
-    return torch.abs(network_output - gt).mean()
-
-
-def l2_loss(network_output, gt):
-    return ((network_output - gt) ** 2).mean()
-
-
-def _gaussian(window_size: int, sigma: float) -> torch.Tensor:
-    g = torch.tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)],
-                     dtype=torch.float32)
-    return g / g.sum()
-
-
-def create_window(window_size: int, channel: int) -> torch.Tensor:
-    w1 = _gaussian(window_size, 1.5).unsqueeze(1)
-    w2 = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0)
-    return w2.expand(channel, 1, window_size, window_size).contiguous()
-
-
-def ssim(img1, img2, window_size: int = 11, size_average: bool = True):
-    """Returns (mean SSIM, SSIM map) like the reference (loss_utils.py:33-63)."""
-    channel = img1.size(-3)
-    window = create_window(window_size, channel).to(device=img1.device, dtype=img1.dtype)
-    pad = window_size // 2
-    mu1 = F.conv2d(img1, window, padding=pad, groups=channel)
-    mu2 = F.conv2d(img2, window, padding=pad, groups=channel)
-    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
-    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=channel) - mu1_sq
-    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=channel) - mu2_sq
-    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=channel) - mu1_mu2
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
-    if size_average:
-        return ssim_map.mean(), ssim_map
-    return ssim_map.mean(1).mean(1).mean(1), ssim_map
-
-
-_SOBEL_Y = [[1, 2, 1], [0, 0, 0], [-1, -2, -1]]
-_SOBEL_X = [[1, 0, -1], [2, 0, -2], [1, 0, -1]]
-
-
-def sobel_loss(render, target):
-    """Returns (mean squared Sobel difference, its map); the 3x3 kernels sum over the three channels (sobel_loss.py:15-16)."""
-    kx = torch.tensor(_SOBEL_X, dtype=torch.float32, device=render.device).unsqueeze(0).expand(1, 3, 3, 3)
-    ky = torch.tensor(_SOBEL_Y, dtype=torch.float32, device=render.device).unsqueeze(0).expand(1, 3, 3, 3)
-    rx = F.conv2d(render.unsqueeze(0), kx, stride=1, padding=1)
-    tx = F.conv2d(target.unsqueeze(0), kx, stride=1, padding=1)
-    ry = F.conv2d(render.unsqueeze(0), ky, stride=1, padding=1)
-    ty = F.conv2d(target.unsqueeze(0), ky, stride=1, padding=1)
-    diff = torch.square(rx - tx) + torch.square(ry - ty)
-    return diff.mean(), diff
-
-
-def image_loss_torch(image, target, l1_weight=0.2, l2_weight=0.1, ssim_weight=0.5, sobel_weight=0.2):
-    """The reference's weighted sum (train_pano2gaussian_decoder.py:246-261, defaults :36-40) from the torch ops."""
-    terms = torch.stack([l1_loss(image, target), l2_loss(image, target), 1.0 - ssim(image, target)[0],
-                         sobel_loss(image, target)[0]])
-    w = torch.tensor([l1_weight, l2_weight, ssim_weight, sobel_weight], dtype=terms.dtype, device=terms.device)
-    return (terms * w).sum(), terms
 
 
 class _FusedImageLoss(torch.autograd.Function):
@@ -115,3 +56,51 @@ def fused_image_loss(image, target, l1_weight=0.2, l2_weight=0.1, ssim_weight=0.
     """(total, terms[5] = L1, L2, 1-SSIM, Sobel, total): same value and d/d(image) as `image_loss_torch`, three HIP
     launches instead of ~60 torch kernels.  `target` receives no gradient."""
     return _FusedImageLoss.apply(image, target, (l1_weight, l2_weight, ssim_weight, sobel_weight))
+
+
+class PerceptualStandIn(torch.nn.Module):
+    """perc(target, image) of main/loss_utils/lpips.py:16-34 with a fixed random VGG16-shaped trunk (see the module
+    docstring).  forward(image [3,H,W] in [0,1], target [3,H,W]) -> scalar; gradients flow into `image` only."""
+    CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512)
+    TAPS = (1, 3, 6, 9, 12)       # index of the convolution after whose ReLU a feature map is taken
+
+    def __init__(self, seed: int = 1234, width_div: int = 1):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        convs, cin = [], 3
+        for v in self.CFG:
+            if v == "M":
+                continue
+            cout = max(4, v // width_div)
+            conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+            with torch.no_grad():   # He initialisation keeps the activations O(1) through the 13 layers
+                conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+                conv.bias.zero_()
+            convs.append(conv)
+            cin = cout
+        self.convs = torch.nn.ModuleList(convs)
+        self.lin = torch.nn.ParameterList([torch.nn.Parameter(torch.rand(self.convs[t].out_channels, generator=g))
+                                           for t in self.TAPS])
+        self.requires_grad_(False)
+
+    def features(self, img):
+        x = (img.unsqueeze(0) * 2.0 - 1.0)
+        if x.shape[2] > 256:
+            x = F.interpolate(x, size=(256, 256), mode="area")     # lpips.py:23-26
+        feats, ci = [], 0
+        for v in self.CFG:
+            if v == "M":
+                x = F.max_pool2d(x, 2)
+                continue
+            x = F.relu(self.convs[ci](x))
+            if ci in self.TAPS:
+                k = self.TAPS.index(ci)
+                n = x / (x.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+                feats.append((n * (self.lin[k] / (x.shape[2] * x.shape[3])).sqrt()[None, :, None, None]).flatten(1))
+            ci += 1
+        return torch.cat(feats, 1)
+
+    def forward(self, image, target):
+        with torch.no_grad():
+            ft = self.features(target)
+        return (self.features(image) - ft).square().sum()

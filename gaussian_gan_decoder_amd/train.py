@@ -2,15 +2,26 @@
 
 One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests).  The raster
 of one frame does not shard; the LATENT BATCH does: each rank decodes and renders `scenes_per_rank` scenes
-(feature planes, positions, camera, target), then ONE flat fp32 gradient all-reduce (sum, / world) -- the reference's
+(feature planes, positions, camera, target), then the flat fp32 gradient all-reduce (sum, / world) -- the reference's
 own pattern eg3d/training/training_loop.py:288-299 -- and an Adam step.  Initial parameters are broadcast from rank
 0 (training_loop.py:196).
 
 The step mirrors main/train_pano2gaussian_decoder.py:217-265 with the parts that are out of scope replaced by
-synthetic stand-ins (SURVEY.md section 7 "hard parts", last item): the GAN that produces feature planes and target
-images is a per-scene learnable plane tensor + a fixed synthetic target; the loss is L1 (+ L2), the only image
-losses without external networks.  What is kept exactly: decoder -> GaussianModel attribute assignment (:223-227)
--> CustomCam (:231) -> render_simple (:232) -> loss -> backward -> Adam (lr 9e-5, :32,213).
+synthetic stand-ins of the same SIZE (SURVEY.md section 7 "hard parts", last item):
+  * the GAN that produces feature planes and target images: a shared learnable plane tensor modulated per scene + a fixed
+    synthetic target;
+  * the finetuned generator backbone whose gradients the reference all-reduces (sequential_decoder_reverse.py:89-99,
+    ~29.6 M parameters ~ 119 MB fp32): `backbone_params` floats that receive a dense gradient every step, are
+    all-reduced and Adam-stepped with everything else;
+  * the LPIPS term (main/loss_utils/lpips.py:6-34): losses.PerceptualStandIn, a fixed random VGG16-shaped trunk.
+What is kept exactly: decoder -> GaussianModel attribute assignment (:223-227) -> CustomCam (:231) -> render_simple
+(:232) -> L1 / L2 / SSIM / Sobel with the reference's weights (:36-40, :246-261) -> backward -> Adam (lr 9e-5, :32,213).
+
+Host-side design for N GPUs: the gradients of all parameters live in ONE persistent flat fp32 buffer (p.grad are views),
+cut into buckets of <= 32 MB; after backward every bucket's all-reduce is launched asynchronously and the Adam step of
+bucket k runs as soon as ITS all-reduce has finished (the later buckets are still in flight).  The local scenes run on
+their own HIP streams, each with its own rasterizer context (ggd_ctx is per (device, stream)), so the rasters of the
+scenes of one rank overlap on the GPU and a scene's num_rendered read-back only waits for that scene's stream.
 """
 from __future__ import annotations
 
@@ -21,8 +32,10 @@ import torch
 
 from .cameras import CustomCam, look_at_cam2world
 from .decoder import SequentialDecoderReverse
-from .losses import fused_image_loss, image_loss_torch
+from .losses import fused_image_loss, PerceptualStandIn
 from .gaussian_model import GaussianModel
+
+BUCKET_BYTES = 32 << 20
 
 
 @dataclass
@@ -58,23 +71,25 @@ def make_scene_batch(scene_ids, n_points: int, size: int, device, seed: int = 0)
 
 
 class DecoderTrainer:
-    """Holds the replicated decoder + per-scene feature planes, runs fwd/bwd for the local scenes and the
-    flat gradient all-reduce."""
+    """Holds the replicated decoder + shared feature planes (+ backbone stand-in), runs fwd/bwd for the local scenes, the
+    bucketed gradient all-reduce and Adam."""
 
     def __init__(self, device, n_scenes_total: int, plane_res: int = 256, plane_channels: int = 32,
                  hidden_dim: int = 128, lr: float = 9e-5, image_size: int = 512, render_fn=None, seed: int = 0,
                  l1_weight: float = 0.2, l2_weight: float = 0.1, ssim_weight: float = 0.5, sobel_weight: float = 0.2,
-                 fused_loss: bool = False, process_group=None, fused_activations: bool = False,
-                 fused_decoder: bool = False):
+                 loss_fn=None, process_group=None, fused_activations: bool = False, fused_decoder: bool = False,
+                 backbone_params: int = 0, perceptual_weight: float = 0.0, perceptual_width_div: int = 1,
+                 scene_streams: bool = True, fused_loss: bool = True):
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.pg = process_group
         self.device = torch.device(device)
         self.image_size = image_size
-        # loss weights: the reference's defaults (train_pano2gaussian_decoder.py:36-40); the LPIPS / identity terms need
-        # external networks and are out of scope
+        # loss weights: the reference's defaults (train_pano2gaussian_decoder.py:36-40)
         self.loss_w = dict(l1_weight=l1_weight, l2_weight=l2_weight, ssim_weight=ssim_weight, sobel_weight=sobel_weight)
-        self.fused_loss = bool(fused_loss)   # csrc/ggd_imgloss.hip instead of the torch conv graph
+        # loss_fn(image, target, **weights) -> (total, terms); default: the fused HIP kernel (csrc/ggd_imgloss.hip).  The
+        # CPU (gloo) tests inject the torch evaluation from tests/.
+        self.loss_fn = loss_fn if loss_fn is not None else fused_image_loss
         torch.manual_seed(seed)
         self.decoder = SequentialDecoderReverse(plane_channels, hidden_dim).to(self.device)
         # stand-in for the finetuned GAN backbone (shared, replicated, all-reduced like the reference's G): ONE learnable
@@ -83,15 +98,27 @@ class DecoderTrainer:
         self.planes = torch.nn.Parameter(
             (0.5 * torch.randn(3, plane_channels, plane_res, plane_res, generator=g)).to(self.device))
         self.latents = (1.0 + 0.25 * torch.randn(n_scenes_total, plane_channels, generator=g)).to(self.device)
+        # the rest of the backbone's gradient payload (see the module docstring): a dense gradient every step through a
+        # fixed probe vector, so that its all-reduce and Adam step do real work
+        self.backbone = None
+        if backbone_params > 0:
+            self.backbone = torch.nn.Parameter(torch.zeros(int(backbone_params), device=self.device))
+            self.backbone_probe = torch.randn(int(backbone_params), generator=g).to(self.device)
+        self.perceptual_weight = float(perceptual_weight)
+        self.perceptual = None
+        if self.perceptual_weight > 0:
+            self.perceptual = PerceptualStandIn(seed=seed + 99, width_div=perceptual_width_div).to(self.device)
+            if self.device.type == "cuda":
+                self.perceptual = self.perceptual.to(memory_format=torch.channels_last)
         # fused_decoder: bf16-MFMA decoder kernels (forward + activation backward) instead of the PyTorch module
         self.decoder_fwd = self.decoder
         self.fused_decoder = bool(fused_decoder)
         if fused_decoder:
             from .fused_decoder import FusedTrainDecoder
             self.decoder_fwd = FusedTrainDecoder(self.decoder)
-        self.params = self.decoder.get_params_custom() + [self.planes]
+        self.params = self.decoder.get_params_custom() + [self.planes] + ([self.backbone] if self.backbone is not None else [])
         self.broadcast_parameters()
-        self.optim = torch.optim.Adam([{"params": self.params, "lr": lr}])
+        self._setup_flat_gradients(lr)
         if render_fn is None:
             from .gaussian_renderer import render_simple
             render_fn = render_simple
@@ -99,7 +126,32 @@ class DecoderTrainer:
         # fused_activations: sigmoid / exp / normalize inside the raster kernels (HIP render_simple only)
         self.render_kwargs = {"fused_activations": True} if fused_activations else {}
         self.bg = torch.tensor([0.55717, 0.52256, 0.51045], dtype=torch.float32, device=self.device)
-        self.gaussians = GaussianModel(0)
+        self.use_streams = bool(scene_streams) and self.device.type == "cuda"
+        self._streams = []
+        self.last_allreduce_bytes = 0
+
+    # ---- gradients: one persistent flat buffer, bucketed --------------------------------------------------------------
+    def _setup_flat_gradients(self, lr):
+        """p.grad of every parameter is a view into self.flat_grad (autograd accumulates into an existing .grad in
+        place); buckets are contiguous slices of <= BUCKET_BYTES (a parameter larger than that is split by the slice
+        boundaries only for the all-reduce, it stays one Adam tensor of the bucket where it starts)."""
+        total = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        off = 0
+        self.buckets = []          # (start, end, [params])
+        cur_start, cur_params = 0, []
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat_grad[off:off + n].view_as(p)
+            cur_params.append(p)
+            off += n
+            if (off - cur_start) * 4 >= BUCKET_BYTES:
+                self.buckets.append((cur_start, off, cur_params))
+                cur_start, cur_params = off, []
+        if cur_params:
+            self.buckets.append((cur_start, off, cur_params))
+        # an all-reduce chunk never exceeds BUCKET_BYTES: slice large buckets (one big parameter) for the collective only
+        self.optims = [torch.optim.Adam([{"params": ps, "lr": lr}]) for _, _, ps in self.buckets]
 
     @property
     def world(self):
@@ -114,25 +166,59 @@ class DecoderTrainer:
             for p in self.params:
                 self.dist.broadcast(p.data, src=0, group=self.pg)
 
-    def allreduce_gradients(self):
-        """ONE flat fp32 all-reduce over every parameter that has a gradient (identical set on all ranks)."""
-        if not self.dist or self.world == 1:
-            return 0
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.pg)
-        flat /= self.world
-        torch.nan_to_num(flat, nan=0.0, posinf=1e5, neginf=-1e5, out=flat)
-        off = 0
-        for p, g in zip(self.params, grads):
-            n = g.numel()
-            p.grad = flat[off:off + n].view_as(p).clone() if p.grad is None else p.grad.copy_(flat[off:off + n].view_as(p))
-            off += n
-        return flat.numel() * 4
+    def allreduce_and_step(self):
+        """Launch every bucket's all-reduce (async), then per bucket: wait -> / world -> sanitise -> Adam.  Bucket k's Adam
+        runs while the all-reduces of buckets k+1.. are still in flight."""
+        world = self.world
+        works = []
+        nbytes = 0
+        if self.dist and world > 1:
+            chunk = BUCKET_BYTES // 4
+            for (s, e, _) in self.buckets:
+                ws = []
+                for c0 in range(s, e, chunk):
+                    c1 = min(e, c0 + chunk)
+                    ws.append(self.dist.all_reduce(self.flat_grad[c0:c1], op=self.dist.ReduceOp.SUM, group=self.pg,
+                                                   async_op=True))
+                    nbytes += (c1 - c0) * 4
+                works.append(ws)
+        for k, (s, e, _) in enumerate(self.buckets):
+            if works:
+                for w in works[k]:
+                    w.wait()
+                g = self.flat_grad[s:e]
+                g /= world
+                torch.nan_to_num(g, nan=0.0, posinf=1e5, neginf=-1e5, out=g)
+            self.optims[k].step()
+        self.last_allreduce_bytes = nbytes
+        return nbytes
+
+    # ---- forward ------------------------------------------------------------------------------------------------------
+    def _scene_loss(self, batch, b, scene_id, attrs):
+        gs = GaussianModel(0)    # one container per in-flight scene (its tensors are saved by autograd until backward)
+        if attrs is not None:
+            gs._xyz, gs._scaling, gs._rotation, gs._opacity, color = attrs[b]
+            gs._features_dc = color.unsqueeze(1)
+        else:
+            planes = self.planes * self.latents[scene_id][None, :, None, None]
+            out = self.decoder_fwd(planes, batch.positions[b])
+            gs._xyz, gs._scaling, gs._rotation = out.xyz, out.scale, out.rotation
+            gs._opacity, gs._features_dc = out.opacity, out.color.unsqueeze(1)
+        fov = float(batch.fov_deg[b]) / 360 * 2 * math.pi
+        # the 4x4 algebra of the camera prologue on the host (a device-side inverse is a solver call with a host
+        # sync and ~40 tiny launches per scene), the three matrices uploaded once
+        cam = CustomCam(size=self.image_size, fov=fov, extr=batch.cam2world[b].cpu())
+        for name in ("world_view_transform", "full_proj_transform", "camera_center"):
+            setattr(cam, name, getattr(cam, name).to(self.device, non_blocking=True))
+        image = self.render_fn(cam, gs, bg_color=self.bg, **self.render_kwargs)["render"][:3]
+        target = batch.target[b]
+        loss = self.loss_fn(image, target, **self.loss_w)[0]
+        if self.perceptual is not None:
+            loss = loss + self.perceptual_weight * self.perceptual(image, target)
+        return loss
 
     def local_loss(self, batch: SceneBatch):
         """Decoder + raster forward for the local scenes; returns the mean loss over them."""
-        total = 0.0
         B = batch.positions.shape[0]
         scene_ids = batch.scene_id.tolist()
         attrs = None
@@ -140,32 +226,33 @@ class DecoderTrainer:
             from .fused_decoder import split_attrs
             attrs = split_attrs(self.decoder_fwd.forward_scenes(
                 [self.planes * self.latents[s][None, :, None, None] for s in scene_ids], batch.positions))
-        for b in range(B):
-            gs = self.gaussians
-            if attrs is not None:
-                gs._xyz, gs._scaling, gs._rotation, gs._opacity, color = attrs[b]
-                gs._features_dc = color.unsqueeze(1)
-            else:
-                planes = self.planes * self.latents[scene_ids[b]][None, :, None, None]
-                out = self.decoder_fwd(planes, batch.positions[b])
-                gs._xyz, gs._scaling, gs._rotation = out.xyz, out.scale, out.rotation
-                gs._opacity, gs._features_dc = out.opacity, out.color.unsqueeze(1)
-            fov = float(batch.fov_deg[b]) / 360 * 2 * math.pi
-            # the 4x4 algebra of the camera prologue on the host (a device-side inverse is a solver call with a host
-            # sync and ~40 tiny launches per scene), the three matrices uploaded once
-            cam = CustomCam(size=self.image_size, fov=fov, extr=batch.cam2world[b].cpu())
-            for name in ("world_view_transform", "full_proj_transform", "camera_center"):
-                setattr(cam, name, getattr(cam, name).to(self.device, non_blocking=True))
-            image = self.render_fn(cam, gs, bg_color=self.bg, **self.render_kwargs)["render"][:3]
-            target = batch.target[b]
-            loss = (fused_image_loss if self.fused_loss else image_loss_torch)(image, target, **self.loss_w)[0]
-            total = total + loss
-        return total / B
+        losses = []
+        if self.use_streams and B > 1:
+            main = torch.cuda.current_stream(self.device)
+            while len(self._streams) < B:
+                self._streams.append(torch.cuda.Stream(device=self.device))
+            for b in range(B):
+                st = self._streams[b]
+                st.wait_stream(main)                    # the decoder outputs / parameters come from the main stream
+                with torch.cuda.stream(st):
+                    losses.append(self._scene_loss(batch, b, scene_ids[b], attrs))
+            for b in range(B):
+                main.wait_stream(self._streams[b])
+                losses[b].record_stream(main)
+        else:
+            for b in range(B):
+                losses.append(self._scene_loss(batch, b, scene_ids[b], attrs))
+        total = losses[0]
+        for l in losses[1:]:
+            total = total + l
+        total = total / B
+        if self.backbone is not None:
+            total = total + 1e-8 * torch.dot(self.backbone, self.backbone_probe)
+        return total
 
     def step(self, batch: SceneBatch) -> float:
-        self.optim.zero_grad(set_to_none=True)
+        self.flat_grad.zero_()
         loss = self.local_loss(batch)
         loss.backward()
-        self.allreduce_gradients()
-        self.optim.step()
+        self.allreduce_and_step()
         return float(loss.detach())

@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 from gaussian_gan_decoder_amd.decoder import Decoder, SequentialDecoderReverse, sample_from_planes
 from gaussian_gan_decoder_amd.train import DecoderTrainer, make_scene_batch
 
-CFG = dict(n_scenes_total=2, plane_res=16, plane_channels=8, hidden_dim=16, image_size=32, seed=3)
+CFG = dict(plane_res=16, plane_channels=8, hidden_dim=16, image_size=32, seed=3)
 N_POINTS = 300
 
 
@@ -22,9 +22,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _make_trainer():
+def _make_trainer(n_scenes_total=2):
+    """The full step of the bench in miniature: backbone gradient payload (a second all-reduce bucket once it passes
+    BUCKET_BYTES; here it shares the bucket), perceptual stand-in, bucketed flat all-reduce + per-bucket Adam."""
     from _cpu_render import render_simple_cpu
-    tr = DecoderTrainer("cpu", render_fn=render_simple_cpu, lr=1e-3, **CFG)
+    from _torch_losses import image_loss_torch
+    tr = DecoderTrainer("cpu", render_fn=render_simple_cpu, loss_fn=image_loss_torch, lr=1e-3, backbone_params=5000,
+                        perceptual_weight=0.05, perceptual_width_div=16, n_scenes_total=n_scenes_total, **CFG)
     # larger splats so the 32x32 image actually sees the 300 points
     tr.decoder.scale_decoder.backbone[-1].bias.data += 3.0
     return tr
@@ -36,7 +40,10 @@ def _worker(rank, world, port, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    tr = _make_trainer()
+    import gaussian_gan_decoder_amd.train as T
+    T.BUCKET_BYTES = 8192      # several buckets and several all-reduce chunks per bucket even at this toy size
+    tr = _make_trainer(world)
+    assert len(tr.buckets) >= 2
     losses = []
     for it in range(2):
         batch = make_scene_batch([rank], N_POINTS, CFG["image_size"], "cpu", seed=it)   # one scene per rank
@@ -46,23 +53,28 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_step_matches_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_data_parallel_step_matches_single_process(tmp_path, world):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0 = torch.load(tmp_path / "rank0.pt"); r1 = torch.load(tmp_path / "rank1.pt")
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    r0 = rs[0]
     # replicas stay bit-identical after the all-reduced steps
-    assert torch.equal(r0["flat"], r1["flat"])
-    # and equal the single-process run over the global batch of 2 scenes (mean loss == mean of per-rank means)
-    tr = _make_trainer()
+    for r in rs[1:]:
+        assert torch.equal(r0["flat"], r["flat"])
+    # and equal the single-process run over the global batch (mean loss == mean of per-rank means)
+    tr = _make_trainer(world)
     ref_losses = []
     for it in range(2):
-        batch = make_scene_batch([0, 1], N_POINTS, CFG["image_size"], "cpu", seed=it)
+        batch = make_scene_batch(list(range(world)), N_POINTS, CFG["image_size"], "cpu", seed=it)
         ref_losses.append(tr.step(batch))
     ref = torch.cat([p.detach().reshape(-1) for p in tr.params])
     assert torch.allclose(r0["flat"], ref, rtol=1e-4, atol=1e-6), float((r0["flat"] - ref).abs().max())
-    assert abs(0.5 * (r0["losses"][0] + r1["losses"][0]) - ref_losses[0]) < 1e-5
+    # (the backbone stand-in's term is added once per rank, so it appears `world` times in the rank mean)
+    bb = float(1e-8 * torch.dot(torch.zeros(1), torch.zeros(1)))
+    assert abs(sum(r["losses"][0] for r in rs) / world - ref_losses[0]) < 1e-5 + abs(bb)
     # the step actually trained something
-    tr0 = _make_trainer()
+    tr0 = _make_trainer(world)
     init = torch.cat([p.detach().reshape(-1) for p in tr0.params])
     assert (ref - init).abs().max() > 1e-5
 
