@@ -427,15 +427,14 @@ def main():
         # (1) the reference's precision: decoder MLPs in fp32 (PyTorch GEMMs, split-K weight gradients)
         train = run_train(False)
         train["mlp_dtype"] = "fp32"
-        train["step"] = ("tri-plane gather (HIP) -> decoder MLPs (PyTorch fp32) -> HIP raster fwd (activations fused), one "
-                         "stream + rasterizer context per scene -> " + LOSS + " -> bwd -> bucketed flat all-reduce "
+        train["step"] = ("tri-plane gather (HIP) -> decoder MLPs (PyTorch fp32) -> HIP raster fwd (activations fused) -> " + LOSS + " -> bwd -> bucketed flat all-reduce "
                          "overlapped with per-bucket Adam")
         # (2) SURVEY 8f row 1: decoder forward / activation backward / weight gradients as bf16-MFMA HIP kernels
         #     (fp32 accumulate, fp32 master weights and optimizer) -- reported beside (1), never instead of it
         train_fused = run_train(True)
         train_fused["mlp_dtype"] = "bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16)"
         train_fused["step"] = ("tri-plane gather (HIP) -> fused 5-head decoder (HIP MFMA fwd, bwd, split-K wgrad; all "
-                               "local scenes in one launch) -> HIP raster fwd per scene stream -> " + LOSS + " -> bwd -> "
+                               "local scenes in one launch) -> HIP raster fwd -> " + LOSS + " -> bwd -> "
                                "bucketed flat all-reduce overlapped with per-bucket Adam")
         # (3) the same step without the two stand-ins (what round 1 measured), for continuity
         train_fused["without_stand_ins"] = run_train(True, standins=False)
