@@ -34,7 +34,8 @@ def _hipcc() -> str:
 def flags() -> list[str]:
     return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
             "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics", "-fno-gpu-rdc",
-            "-Wall", "-Wno-unused-function", "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC]
+            "-Wall", "-Wno-unused-function", "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC] + \
+        os.environ.get("GGD_EXTRA_HIPCC_FLAGS", "").split()
 
 
 OBJ_DIR = os.path.join(_PKG, "build")

@@ -237,10 +237,18 @@ __global__ __launch_bounds__(RS_THREADS) void sort_global_hist_kernel(const KeyT
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * (RS_THREADS * ITEMS);
   const int lane = threadIdx.x & 63;
-#pragma unroll 4
+  // all ITEMS loads of the lane are issued before the first key is consumed (one workgroup per CU: the kernel is bound
+  // by the latency of its loads, not by their bandwidth)
+  KeyT kreg[ITEMS];
+#pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     const int64_t idx = base + (int64_t)k * RS_THREADS + threadIdx.x;
-    const KeyT key = idx < n ? keys[idx] : (KeyT)0;
+    kreg[k] = idx < n ? keys[idx] : (KeyT)0;
+  }
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int64_t idx = base + (int64_t)k * RS_THREADS + threadIdx.x;
+    const KeyT key = kreg[k];
     const bool ok = idx < n && !(SKIP && key == (KeyT)~(KeyT)0);
     const uint64_t act = __ballot(ok);
     if (act == 0ull) continue;

@@ -27,4 +27,6 @@ for k in sorted(acc, key=lambda n: -sum(durs.get(n, [0])) / max(1, len(durs.get(
           f"   wave_cycles(quad)={wc:.3e} busy_cycles={f('SQ_BUSY_CYCLES'):.3e}  fractions of wave cycles: VALU_active={f('SQ_ACTIVE_INST_VALU') / wc:.3f} "
           f"SCA_active={f('SQ_ACTIVE_INST_SCA') / wc:.3f} LDS_active={f('SQ_ACTIVE_INST_LDS') / wc:.3f} any_active={f('SQ_ACTIVE_INST_ANY') / wc:.3f} "
           f"wait_any={f('SQ_WAIT_ANY') / wc:.3f} wait_inst_any={f('SQ_WAIT_INST_ANY') / wc:.3f} wait_inst_lds={f('SQ_WAIT_INST_LDS') / wc:.3f}\n"
-          f"   LDS_idx_active={f('SQ_LDS_IDX_ACTIVE'):.3e} LDS_bank_conflict={f('SQ_LDS_BANK_CONFLICT'):.3e}  FETCH_KiB={f('FETCH_SIZE'):.0f} WRITE_KiB={f('WRITE_SIZE'):.0f}")
+          f"   LDS_idx_active={f('SQ_LDS_IDX_ACTIVE'):.3e} LDS_bank_conflict={f('SQ_LDS_BANK_CONFLICT'):.3e}  FETCH_KiB={f('FETCH_SIZE'):.0f} WRITE_KiB={f('WRITE_SIZE'):.0f}\n"
+          f"   MFMA: insts={f('SQ_INSTS_MFMA'):.3e} mops_bf16={f('SQ_INSTS_VALU_MFMA_MOPS_BF16'):.3e} busy_cycles={f('SQ_VALU_MFMA_BUSY_CYCLES'):.3e} "
+          f"GRBM_GUI_ACTIVE={f('GRBM_GUI_ACTIVE'):.3e}")
