@@ -239,6 +239,20 @@ int ggd_trigrid_backward(ggd_ctx* ctx, void* stream, int32_t C, int32_t D, int32
                          const float* pos, int32_t N, float box_warp, const float* dout, float* dgrids_cl);
 
 /*
+ * GPU iso-surface point sampler -- the position generator of the decoder training step, replacing the CPU marching
+ * cubes + trimesh + D2H/H2D hop of main/decoder_utils/target_dataloader.py:96-118,172-176: density grid sigma[n][n][n]
+ * ([x][y][z], z fastest, main/marching_cube/sample.py:15-17) -> iso-surface at `level` (reference: 10) by marching
+ * tetrahedra -> num_points positions, point i on face (i mod F) of pass (i div F) with barycentric weights rand(3)/sum
+ * (:104-110), in the reference's units (index / n - 0.5, :99-101), scaled by clip(1 + thickness * N(0,1), 0, 1)
+ * (:113-116).  No host sync: the face count F stays on the device (*num_faces, a DEVICE uint32; 0 -> positions are
+ * zero-filled).  Pure function of (sigma, level, seed).  tmp: ggd_surface_tmp_bytes(n) bytes of device scratch.
+ */
+size_t ggd_surface_tmp_bytes(int32_t n);
+int ggd_surface_sample(ggd_ctx* ctx, void* stream, const float* sigma, int32_t n, float level, int32_t num_points,
+                       float thickness, uint64_t seed, float* positions, uint32_t* num_faces, void* tmp,
+                       size_t tmp_bytes);
+
+/*
  * Fused per-point decoder, inference (bf16 MFMA, fp32 accumulate): the 5 chained `Decoder` MLPs of
  * main/decoder_models/sequential_decoder_reverse.py:68-85 in ONE launch.
  *   feat  [N,32]  mean-of-planes features (ggd_triplane_forward)      pos [N,3] positions
