@@ -250,3 +250,74 @@ class SequentialDecoderReverse(nn.Module):
                   self.color_decoder):
             params += list(m.parameters())
         return params
+
+
+class SequentialDecoder(nn.Module):
+    """The forward-ordered chain (main/decoder_models/sequential_decoder.py:27-84, decoder_type "sequential"):
+    xyz -> scale -> rotation -> opacity -> colour, every head seeing [plane_mean, position, earlier outputs]; scale
+    activation -softplus(s + 5) - 2 (NOT -2.5 as in the reversed chain).  Same parameter names as the reference."""
+
+    def __init__(self, plane_channels=32, hidden_dim=128, position_dim=3, box_warp=1.0, plane_axes="eg3d",
+                 triplane_depth=None):
+        super().__init__()
+        if position_dim != 3:
+            raise NotImplementedError("positional encoding of the positions (use_xyz_embedding) is not implemented")
+        f = plane_channels + position_dim
+        self.box_warp, self.plane_axes, self.triplane_depth = box_warp, plane_axes, triplane_depth
+        self.xyz_decoder = Decoder(f, 3, hidden_dim)
+        self.scale_decoder = Decoder(f + 3, 3, hidden_dim)
+        self.rotation_decoder = Decoder(f + 6, 4, hidden_dim)
+        self.opacity_decoder = Decoder(f + 10, 1, hidden_dim)
+        self.color_decoder = Decoder(f + 11, 3, hidden_dim)
+        self.scale_activation = nn.Softplus()
+
+    def activate_scale(self, scale):
+        return -self.scale_activation(scale + 5) - 2
+
+    def forward(self, feature_planes, init_position):
+        pf = triplane_mean(feature_planes, init_position, self.box_warp, self.plane_axes, self.triplane_depth)
+        info = init_position
+        xyz = self.xyz_decoder(pf, info) * 0.01 + init_position
+        info = torch.concat([info, xyz], dim=-1)
+        scale = self.activate_scale(self.scale_decoder(pf, info))
+        info = torch.concat([info, scale], dim=-1)
+        rotation = self.rotation_decoder(pf, info)
+        info = torch.concat([info, rotation], dim=-1)
+        opacity = self.opacity_decoder(pf, info)
+        info = torch.concat([info, opacity], dim=-1)
+        color = self.color_decoder(pf, info)
+        return SimpleNamespace(xyz=xyz, scale=scale, rotation=rotation, opacity=opacity, color=color)
+
+    get_params_custom = SequentialDecoderReverse.get_params_custom
+
+
+class ParallelDecoder(nn.Module):
+    """Five independent heads on [plane_mean, position] (main/decoder_models/parallel_decoder.py:27-80, decoder_type
+    "parallel"); scale activation -softplus(s + 5) - 2."""
+
+    def __init__(self, plane_channels=32, hidden_dim=128, position_dim=3, box_warp=1.0, plane_axes="eg3d",
+                 triplane_depth=None):
+        super().__init__()
+        if position_dim != 3:
+            raise NotImplementedError("positional encoding of the positions (use_xyz_embedding) is not implemented")
+        f = plane_channels + position_dim
+        self.box_warp, self.plane_axes, self.triplane_depth = box_warp, plane_axes, triplane_depth
+        self.xyz_decoder = Decoder(f, 3, hidden_dim)
+        self.scale_decoder = Decoder(f, 3, hidden_dim)
+        self.rotation_decoder = Decoder(f, 4, hidden_dim)
+        self.opacity_decoder = Decoder(f, 1, hidden_dim)
+        self.color_decoder = Decoder(f, 3, hidden_dim)
+        self.scale_activation = nn.Softplus()
+
+    def activate_scale(self, scale):
+        return -self.scale_activation(scale + 5) - 2
+
+    def forward(self, feature_planes, init_position):
+        pf = triplane_mean(feature_planes, init_position, self.box_warp, self.plane_axes, self.triplane_depth)
+        pos = init_position
+        return SimpleNamespace(xyz=self.xyz_decoder(pf, pos) * 0.01 + init_position,
+                               scale=self.activate_scale(self.scale_decoder(pf, pos)),
+                               rotation=self.rotation_decoder(pf, pos), opacity=self.opacity_decoder(pf, pos),
+                               color=self.color_decoder(pf, pos))
+
+    get_params_custom = SequentialDecoderReverse.get_params_custom

@@ -22,6 +22,8 @@ sys.path.insert(0, os.path.join(REF, "eg3d"))            # dnnlib, torch_utils, 
 
 from training.volumetric_rendering.renderer import generate_planes   # noqa: E402
 from main.decoder_models.sequential_decoder_reverse import SequentialDecoderReverse  # noqa: E402
+from main.decoder_models.sequential_decoder import SequentialDecoder  # noqa: E402
+from main.decoder_models.parallel_decoder import ParallelDecoder  # noqa: E402
 
 
 class StubG(torch.nn.Module):
@@ -59,6 +61,20 @@ def main():
                         rotation=out.rotation.numpy(), scale=out.scale.numpy(), xyz=out.xyz.numpy(), **sd)
     print("wrote sequential_decoder_fixture.npz;", {k: tuple(v.shape) for k, v in out.items()},
           "keys", sorted(sd)[:4], "...")
+    # the two other decoder types of main/train_pano2gaussian_decoder.py:170-192 on the same planes / positions
+    for cls, tag, seed in ((SequentialDecoder, "forward_chain", 33), (ParallelDecoder, "parallel", 34)):
+        torch.manual_seed(seed)
+        d2 = cls(StubG(planes), hidden_dim=128, use_xyz_embedding=False, use_gen_finetune=False, device="cpu")
+        with torch.no_grad():
+            for n, p in d2.named_parameters():
+                if p.dim() == 2:
+                    p.mul_(1.5)
+            o2 = d2(torch.zeros(1, 512), torch.zeros(1, 25), pos, 1.0)
+        sd2 = {"sd_" + k: v.numpy() for k, v in d2.state_dict().items() if "decoder" in k}
+        np.savez_compressed(os.path.join(HERE, f"{tag}_decoder_fixture.npz"), color=o2.color.numpy(),
+                            opacity=o2.opacity.numpy(), rotation=o2.rotation.numpy(), scale=o2.scale.numpy(),
+                            xyz=o2.xyz.numpy(), **sd2)
+        print(f"wrote {tag}_decoder_fixture.npz")
 
 
 if __name__ == "__main__":

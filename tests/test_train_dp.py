@@ -115,3 +115,22 @@ def test_sequential_decoder_matches_reference_class_fixture():
         out = dec(torch.from_numpy(f["planes"]), torch.from_numpy(f["positions"]))
     for k in ("color", "opacity", "rotation", "scale", "xyz"):
         np.testing.assert_allclose(getattr(out, k).numpy(), f[k], atol=2e-5, rtol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("tag", ["forward_chain", "parallel"])
+def test_other_decoder_types_match_reference_class_fixtures(tag):
+    """decoder_type "sequential" / "parallel" of main/train_pano2gaussian_decoder.py:170-192: outputs of the reference's
+    SequentialDecoder / ParallelDecoder (main/decoder_models/sequential_decoder.py:38-84, parallel_decoder.py:38-80) on the
+    planes / positions of sequential_decoder_fixture.npz; our modules load their state_dict unchanged."""
+    from gaussian_gan_decoder_amd.decoder import SequentialDecoder, ParallelDecoder
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    base = np.load(os.path.join(here, "sequential_decoder_fixture.npz"))
+    f = np.load(os.path.join(here, f"{tag}_decoder_fixture.npz"))
+    dec = (SequentialDecoder if tag == "forward_chain" else ParallelDecoder)()
+    missing, unexpected = dec.load_state_dict({k[3:]: torch.from_numpy(f[k]) for k in f.files if k.startswith("sd_")}, strict=False)
+    assert not unexpected and not [m for m in missing if "decoder" in m], (missing, unexpected)
+    with torch.no_grad():
+        out = dec(torch.from_numpy(base["planes"]), torch.from_numpy(base["positions"]))
+    for k in ("color", "opacity", "rotation", "scale", "xyz"):
+        np.testing.assert_allclose(getattr(out, k).numpy(), f[k], atol=2e-5, rtol=1e-5, err_msg=k)
+    assert (out.scale <= -2.0).all()
