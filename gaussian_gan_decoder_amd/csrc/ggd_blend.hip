@@ -774,9 +774,6 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
   return GGD_OK;
 }
 
-// auto: below this many tiles the backward runs two waves per tile (measured: see DESIGN.md)
-constexpr int GGD_BWD_SPLIT_MAX_TILES = 4096;
-
 int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
                               const uint32_t* list, const uint32_t* ranges, const float* final_T,
                               const uint32_t* n_contrib, const float* dL_dpix, float* grad_acc) {

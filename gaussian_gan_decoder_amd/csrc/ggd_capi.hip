@@ -241,17 +241,15 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
   uint8_t* clamped = reinterpret_cast<uint8_t*>(gb + gv.clamped);
   uint32_t* depth_keys = reinterpret_cast<uint32_t*>(gb + gv.depth_keys);
   uint2* rect = reinterpret_cast<uint2*>(gb + gv.rect);
-  uint32_t* header = reinterpret_cast<uint32_t*>(gb + gv.header);
 
   const size_t scan_tmp = ggd_scan_tmp_bytes(prm->P);
   rc = ggd_reserve_scratch(ctx, scan_tmp, s);
   if (rc != GGD_OK) return rc;
   if (prm->prefiltered) GGD_HIP(hipMemsetAsync(ctx->d_words + 1, 0, sizeof(uint32_t), s));
-  (void)header;   // reserved words of the geometry buffer (not written by the current kernels)
   {
     StageTimer t(ctx, ST_PREPROCESS, s);
     rc = ggd_launch_preprocess(ctx, s, *prm, means3D, shs, colors_precomp, opacities, scales, rotations,
-                               cov3D_precomp, splat, tiles, shs ? clamped : nullptr, radii, depth_keys, rect, header,
+                               cov3D_precomp, splat, tiles, shs ? clamped : nullptr, radii, depth_keys, rect,
                                ctx->d_words + 1);
     if (rc != GGD_OK) return rc;
   }

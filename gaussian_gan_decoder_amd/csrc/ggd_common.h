@@ -68,7 +68,7 @@ int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, co
                           const float* shs, const float* colors_precomp, const float* opacities,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           ggd_splat* splat, uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii,
-                          uint32_t* depth_keys, uint2* rect, uint32_t* visible_count, uint32_t* trap_flag);
+                          uint32_t* depth_keys, uint2* rect, uint32_t* trap_flag);
 int ggd_launch_mark_visible(ggd_ctx* ctx, hipStream_t s, int P, const float* means3D, const float* view,
                             uint8_t* present);
 // inclusive scan of a uint32 array; total written to *d_total (device)

@@ -152,8 +152,7 @@ int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, co
                           const float* shs, const float* colors_precomp, const float* opacities,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           ggd_splat* splat, uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii,
-                          uint32_t* depth_keys, uint2* rect, uint32_t* visible_count, uint32_t* trap_flag) {
-  (void)visible_count;
+                          uint32_t* depth_keys, uint2* rect, uint32_t* trap_flag) {
   if (prm.P == 0) return GGD_OK;
   const int grid = (prm.P + 255) / 256;
   hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, s, prm.P, prm.M, prm.sh_degree, prm.width,
