@@ -1,0 +1,24 @@
+#!/bin/bash
+# Produce the round's rocprofv3 evidence on the GPU box (run through gpurun):  bash scripts/make_profiles.sh <tag>
+# Outputs under gpurun_out/<tag>/ (copy the summaries into profiles/<tag>/ afterwards with profiles/collect.py):
+#   bench/      rocprofv3 --kernel-trace --stats of the bench command (raster forward + backward, 100 steps)
+#   train/      the same for the fused-decoder train step (scripts/profile_train.py --fused)
+#   pmc/        counter passes (scripts/pmc_passes.sh) of the raster forward + backward, 1 M / 1024^2 cube
+#   pmc_shell/  ... of the shell scene
+#   pmc_mlp/    ... of the fused decoder MLP, inference kernel, 1 M points (incl. the MFMA counters)
+set -u
+TAG=${1:-r02_final}
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/$TAG
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/bench -o p --output-format csv -- \
+    python $R/bench.py --steps 100 --backward --no-train --no-decode --no-sweep --no-cpu-baseline \
+    > $R/gpurun_out/$TAG/bench_under_rocprof.json 2> $R/gpurun_out/$TAG/bench.err
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/train -o p --output-format csv -- \
+    python $R/scripts/profile_train.py --fused > $R/gpurun_out/$TAG/train.log 2>&1
+cd $R
+bash scripts/pmc_passes.sh $TAG/pmc scripts/fwd_only.py 1M_1024_cube 5 --backward > /dev/null
+bash scripts/pmc_passes.sh $TAG/pmc_shell scripts/fwd_only.py 1M_1024_shell 5 --backward > /dev/null
+bash scripts/pmc_passes.sh $TAG/pmc_mlp scripts/mlp_only.py 5 > /dev/null
+python bench.py --no-cpu-baseline > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench_plain.err
+echo done
