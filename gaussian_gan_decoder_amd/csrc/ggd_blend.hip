@@ -70,21 +70,35 @@ __device__ __forceinline__ bool record_box_hits(float x, float y, float ex, floa
   return !(x + ex < wx0 || x - ex > wx1 || y + ey < wy0 || y - ey > wy1);
 }
 
+// Workgroup -> tile placement of the blend kernels (speed only; any placement is correct).  Workgroup b runs on XCD
+// b % 8 and every XCD has its own 4 MB L2: the nsub sub-blocks of one tile take consecutive slots of ONE XCD's dispatch
+// stream (b = 8 q + x: slot q of XCD x), so they are resident together and all but the first gather of a record hit
+// that L2 (measured, 4 waves per tile: FETCH_SIZE 178 -> 46 MB per frame, 156 -> 149 us; with the sub-blocks T
+// workgroups apart the later ones re-fetched every record from the Infinity Cache).  Walking 8x8-tile patches per XCD
+// on top of that halves the fetches again (23 MB) but costs time (151 us; shell 335 -> 354 us): neighbouring tiles
+// finish together and leave the XCDs unevenly loaded -- not used.  Tile counts that are not multiples of 8 keep
+// tile = b % T.
+__device__ __forceinline__ void ggd_block_to_tile(int b, int nsub, int gx, int gy, int T, int& tile, int& sub) {
+  (void)gx; (void)gy;
+  if ((T & 7) == 0) { const int q = b >> 3; sub = q % nsub; tile = (q / nsub) * 8 + (b & 7); }
+  else { tile = b % T; sub = b / T; }
+}
+
 // Wave <-> pixel mapping of the blend kernels: a wave owns a BW x BH pixel block of a 16x16 tile, PXL horizontally
 // adjacent pixels per lane (BW / PXL lanes per row, BH = 64 * PXL / BW rows):
 //   PXL = 4, BW = 16: one wave per tile;      PXL = 2, BW = 16: two waves per tile (16x8 halves);
 //   PXL = 1, BW = 8 : four waves per tile (8x8 quarters).
 // The VALU cost of a blended record is proportional to the pixels a wave holds (packed fp32 brings no throughput on
 // gfx950), while a record typically reaches ~40 % of a 16x8 block: smaller blocks cull finer and leave fewer idle
-// lanes, at the price of more list scans.  The sub-blocks of one tile are T workgroups apart so that they land on the
-// same XCD (block b -> XCD b % 8) and share its L2.
+// lanes, at the price of more list scans.
 template <int PXL, int BW = 16>
 struct WaveGeom {
   static constexpr int LPR = BW / PXL, BH = 64 / LPR, NSX = 16 / BW, NSUB = NSX * (16 / BH);
   int px0, py;
   uint32_t lo, hi;
   __device__ __forceinline__ WaveGeom(int gx, int T, const uint32_t* __restrict__ ranges, uint32_t capacity = 0xffffffffu) {
-    const int tile = (int)blockIdx.x % T, sub = (int)blockIdx.x / T;
+    int tile, sub;
+    ggd_block_to_tile((int)blockIdx.x, NSUB, gx, T / gx, T, tile, sub);
     const int tx = tile % gx, ty = tile / gx;
     const int lane = threadIdx.x;
     px0 = tx * 16 + (sub % NSX) * BW + (lane % LPR) * PXL;
@@ -559,7 +573,7 @@ __device__ __forceinline__ float wave_reduce8_transposed(float (&v)[8]) {
 
 template <int EXP_MODE, bool CULL>
 __global__ __launch_bounds__(128) void blend_backward_wg_kernel(
-    int W, int H, int gx, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ list,
+    int W, int H, int gx, int gy, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ list,
     const uint32_t* __restrict__ ranges, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
   __shared__ float4 s_rec[2][64 * 3];
@@ -569,7 +583,9 @@ __global__ __launch_bounds__(128) void blend_backward_wg_kernel(
   __shared__ uint32_t s_touch[2][2];
   __shared__ uint32_t s_maxn[2];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int tile = blockIdx.x, tx = tile % gx, ty = tile / gx;
+  int tile, sub_unused;
+  ggd_block_to_tile((int)blockIdx.x, 1, gx, gy, gx * gy, tile, sub_unused);
+  const int tx = tile % gx, ty = tile / gx;
   const int px0 = tx * 16 + (lane & 7) * 2, py = ty * 16 + wv * 8 + (lane >> 3);
   const uint2 rg = reinterpret_cast<const uint2*>(ranges)[tile];
   const bool row_in = py < H;
@@ -788,7 +804,7 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
   // 0: one wave per tile (4 px / lane); 2: two independent waves per tile (atomics per half)
   if (split == 1 || split == 3) {
 #define GGD_LAUNCH_BWG(EM, CU)                                                                                          \
-    hipLaunchKernelGGL((blend_backward_wg_kernel<EM, CU>), dim3(T), dim3(128), 0, s, prm.width, prm.height, gx, splat,   \
+    hipLaunchKernelGGL((blend_backward_wg_kernel<EM, CU>), dim3(T), dim3(128), 0, s, prm.width, prm.height, gx, gy, splat, \
                        list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc)
     if (cull) {
       if (em == 0) GGD_LAUNCH_BWG(0, true); else if (em == 1) GGD_LAUNCH_BWG(1, true); else GGD_LAUNCH_BWG(2, true);
