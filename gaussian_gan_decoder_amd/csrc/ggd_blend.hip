@@ -70,6 +70,36 @@ __device__ __forceinline__ bool record_box_hits(float x, float y, float ex, floa
   return !(x + ex < wx0 || x - ex > wx1 || y + ey < wy0 || y - ey > wy1);
 }
 
+// Second, exact stage of the pre-cull (same lane, only for records whose box hit): the largest `power` any point of the
+// wave's pixel rectangle can reach.  power(d) = hA dx^2 + nB dx dy + hC dy^2 (d = centre - pixel) is concave for a
+// positive-definite conic, so its maximum over the rectangle [dx0, dx1] x [dy0, dy1] is 0 if the rectangle contains the
+// centre and otherwise sits on one of the four edges, where it is a 1-D parabola maximised at the clamped vertex.  An
+// elongated, tilted splat whose bounding box clips a block's corner is dropped here instead of costing every lane of
+// the wave a `power` evaluation.  Conservative: the test allows for the fp32 rounding of both evaluations (margin
+// proportional to the magnitude of the three terms); non-positive-definite conics (ex = +inf) are always kept.
+__device__ __forceinline__ bool record_reaches_block(float x, float y, float hA, float nB, float hC, float thr, float ex,
+                                                     float wx0, float wx1, float wy0, float wy1) {
+  if (!(ex < __builtin_huge_valf())) return true;
+  const float dx0 = x - wx1, dx1 = x - wx0, dy0 = y - wy1, dy1 = y - wy0;
+  if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return true;
+  const float ihC = -0.5f / hC, ihA = -0.5f / hA;     // vertex of the edge parabolas: dy* = -nB X / (2 hC), dx* = -nB Y / (2 hA)
+  float pmax = -__builtin_huge_valf(), mag = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float X = e ? dx1 : dx0;
+    const float dyv = fminf(fmaxf((nB * X) * ihC, dy0), dy1);
+    const float t1 = hA * X * X, t2 = nB * X * dyv, t3 = hC * dyv * dyv;
+    pmax = fmaxf(pmax, (t1 + t2) + t3);
+    mag = fmaxf(mag, (fabsf(t1) + fabsf(t2)) + fabsf(t3));
+    const float Y = e ? dy1 : dy0;
+    const float dxv = fminf(fmaxf((nB * Y) * ihA, dx0), dx1);
+    const float u1 = hA * dxv * dxv, u2 = nB * dxv * Y, u3 = hC * Y * Y;
+    pmax = fmaxf(pmax, (u1 + u2) + u3);
+    mag = fmaxf(mag, (fabsf(u1) + fabsf(u2)) + fabsf(u3));
+  }
+  return !(pmax < thr - (1e-3f + 1e-5f * mag));
+}
+
 // Workgroup -> tile placement of the blend kernels (speed only; any placement is correct).  Workgroup b runs on XCD
 // b % 8 and every XCD has its own 4 MB L2: the nsub sub-blocks of one tile take consecutive slots of ONE XCD's dispatch
 // stream (b = 8 q + x: slot q of XCD x), so they are resident together and all but the first gather of a record hit
@@ -200,7 +230,8 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
       q0 = r0;
       q1 = make_float4(r1.x, CULL ? r1.y : -__builtin_huge_valf(), r1.z, __uint_as_float(pos - g.lo + 1u));
       q2 = make_float4(r1.w, r2.x, r2.y, 0.0f);
-      keep = CULL ? record_box_hits(r0.x, r0.y, r2.z, r2.w, wx0, wx1, wy0, wy1) : true;
+      keep = CULL ? (record_box_hits(r0.x, r0.y, r2.z, r2.w, wx0, wx1, wy0, wy1) &&
+                     record_reaches_block(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, wx0, wx1, wy0, wy1)) : true;
     }
   };
   fetch(g.lo + lane);
@@ -638,7 +669,8 @@ __global__ __launch_bounds__(128) void blend_backward_wg_kernel(
       q0 = r0;
       q1 = make_float4(r1.x, CULL ? r1.y : -__builtin_huge_valf(), r1.z, __uint_as_float((cstart - rg.x) + (uint32_t)lane));
       q2 = make_float4(r1.w, r2.x, r2.y, __uint_as_float((uint32_t)lane));
-      keep = CULL ? record_box_hits(r0.x, r0.y, r2.z, r2.w, wx0, wx0 + 15.0f, wy0, wy0 + 7.0f) : true;
+      keep = CULL ? (record_box_hits(r0.x, r0.y, r2.z, r2.w, wx0, wx0 + 15.0f, wy0, wy0 + 7.0f) &&
+                     record_reaches_block(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, wx0, wx0 + 15.0f, wy0, wy0 + 7.0f)) : true;
       if (wv == 0) { s_id[lane] = my_id; s_op[lane] = r1.z; }
     }
     const uint64_t kept = __ballot(keep);
