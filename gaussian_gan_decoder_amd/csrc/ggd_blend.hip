@@ -176,7 +176,7 @@ __device__ __forceinline__ void fma_into(float& acc, float a, float b) {
 // Cost model (issue slots in units of one v_fma_f32, measured by the probe): plain VALU 1, packed fp32 1.85 (no
 // throughput gain over two plain ops on gfx950), v_cmp / VOP3 select / v_min 1.6, v_exp_f32 3.1: cull stage ~12 per
 // staged record, update ~55 per record that some pixel of the wave sees.
-template <int EXP_MODE, bool CULL, int PXL, int BW>
+template <int EXP_MODE, bool CULL, int PXL, int BW, bool STATS>
 __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx, int T,
                                                            const ggd_splat* __restrict__ splat,
                                                            const uint32_t* __restrict__ list,
@@ -235,78 +235,79 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
     }
   };
   fetch(g.lo + lane);
-  bool finished = !wave_alive();
-  for (uint32_t base = g.lo; base < g.hi && !finished; base += 64) {
+  if (!wave_alive()) goto all_done;
+  for (uint32_t base = g.lo; base < g.hi; base += 64) {
     __syncthreads();  // single-wave block: orders the previous round's LDS reads before this round's writes
     const uint64_t kept = __ballot(keep);
     if (keep) {  // compacted: only records whose box reaches this wave's pixels are staged
       const int slot = __popcll(kept & lt_mask);
       s_rec[slot * 3 + 0] = q0; s_rec[slot * 3 + 1] = q1; s_rec[slot * 3 + 2] = q2;
     }
-    st_visited += min(64u, g.hi - base);
-    st_culled += min(64u, g.hi - base) - (uint32_t)__popcll(kept);
+    // the staged list is padded to a multiple of 8 with records no pixel can see (threshold +inf), so that a group of 8
+    // is straight-line code: LDS addresses are immediates, there is no loop counter, and a record that no pixel of the
+    // wave sees costs one scalar branch.  The blend state is updated in place by the tied-operand selects below, inside
+    // a wave-uniform `if` -- nothing is copied where the culled and the updated path join.
+    const int n = __popcll(kept), n8 = (n + 7) & ~7;
+    if (lane >= n && lane < n8) {
+      s_rec[lane * 3 + 0] = make_float4(0, 0, 0, 0);
+      s_rec[lane * 3 + 1] = make_float4(0, __builtin_huge_valf(), 0, 0);
+    }
+    if (STATS) {
+      st_visited += min(64u, g.hi - base);
+      st_culled += min(64u, g.hi - base) - (uint32_t)__popcll(kept);
+    }
     fetch(base + 64 + lane);  // next round's gather is in flight while this round is blended
     __syncthreads();
-    const int n = __popcll(kept);
-    // search-then-update: the inner loop only LOOKS for the next staged record that some pixel of the wave sees (no
-    // blend state is modified there), the update then runs as straight-line code of the outer loop -- so the blend
-    // state is an ordinary loop-carried value (with the update inside an `if` of a single loop the compiler computes it
-    // into fresh registers and copies ~10 of them back where the two paths join)
-    int j = 0;
-    while (true) {
-      float4 b, c;
-      float pw[PXL];
-      uint64_t need[PXL];
-      bool found = false;
-      while (j < n) {
-        if ((j & 7) == 0 && !wave_alive()) { finished = true; break; }
-        const float4 a = s_rec[j * 3 + 0];
-        b = s_rec[j * 3 + 1];
-        c = s_rec[j * 3 + 2];
+    for (int j0 = 0; j0 < n8; j0 += 8) {
+      if (!wave_alive()) goto all_done;
+      const float4* grp = s_rec + j0 * 3;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const float4 a = grp[jj * 3 + 0];
+        const float2 b01 = *reinterpret_cast<const float2*>(grp + jj * 3 + 1);
         const float dy = a.y - pyf;
-        const float nBdy = a.w * dy, hCdy2 = (b.x * dy) * dy;
-        uint64_t any = 0ull;
+        const float nBdy = a.w * dy, hCdy2 = (b01.x * dy) * dy;
+        float pw[PXL];
+        uint64_t need[PXL], any = 0ull;
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
           const float dx = a.x - px[k];
           pw[k] = __builtin_fmaf(__builtin_fmaf(a.z, dx, nBdy), dx, hCdy2);
-          need[k] = __ballot(pw[k] >= b.y);
+          need[k] = __ballot(pw[k] >= b01.y);
           any |= need[k];
         }
-        ++j;
-        if (any != 0ull) { found = true; break; }
-        st_culled += 1;
-      }
-      if (!found) break;
-      if (stats) {
-        uint64_t lanes = 0ull;
+        if (any == 0ull) { if (STATS && j0 + jj < n) st_culled += 1; continue; }
+        if (STATS) {
+          uint64_t lanes = 0ull;
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) { lanes |= need[k]; st_pixels += (uint32_t)__popcll(need[k]); }
-        st_lanes += (uint32_t)__popcll(lanes);
-      }
-      const uint32_t contributor = __float_as_uint(b.w);
+          for (int k = 0; k < PXL; ++k) { lanes |= need[k]; st_pixels += (uint32_t)__popcll(need[k]); }
+          st_lanes += (uint32_t)__popcll(lanes);
+        }
+        const float2 b23 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(grp + jj * 3 + 1) + 2);
+        const float4 c = grp[jj * 3 + 2];
+        const uint32_t contributor = __float_as_uint(b23.y);
 #pragma unroll
-      for (int k = 0; k < PXL; ++k) {
-        // alpha, the thresholds and T <- T (1 - alpha) are evaluated exactly as published; the colour is accumulated as
-        // fma(col, alpha * T, C) (one rounding fewer than (col * alpha) * T + C -- inside the 1e-5 tolerance)
-        const float G = blend_exp<EXP_MODE>(pw[k]);
-        const float alpha = fminf(0.99f, G * b.z);
-        const uint64_t live = need[k] & ~__ballot(pw[k] > 0.0f) & ~__ballot(alpha < ALPHA_FLOOR);
-        const float test_T = Tr[k] * (1.0f - alpha);
-        const uint64_t low = __ballot(test_T < 0.0001f);
-        const uint64_t upd = live & ~low, stop = live & low;
-        const float w = sel_or_zero(alpha * Tr[k], upd);
-        fma_into(C[k][0], c.x, w);
-        fma_into(C[k][1], c.y, w);
-        fma_into(C[k][2], c.z, w);
-        sel_into_after(Tr[k], test_T, upd, w);
-        sel_into(last[k], contributor, upd);
-        sel_into(px[k], INF, stop);
+        for (int k = 0; k < PXL; ++k) {
+          const float G = blend_exp<EXP_MODE>(pw[k]);
+          const float alpha = fminf(0.99f, G * b23.x);
+          const uint64_t live = need[k] & ~__ballot(pw[k] > 0.0f) & ~__ballot(alpha < ALPHA_FLOOR);
+          const float test_T = Tr[k] * (1.0f - alpha);
+          const uint64_t low = __ballot(test_T < 0.0001f);
+          const uint64_t upd = live & ~low, stop = live & low;
+          const float w = sel_or_zero(alpha * Tr[k], upd);
+          fma_into(C[k][0], c.x, w);
+          fma_into(C[k][1], c.y, w);
+          fma_into(C[k][2], c.z, w);
+          sel_into_after(Tr[k], test_T, upd, w);
+          sel_into(last[k], contributor, upd);
+          sel_into(px[k], INF, stop);
+        }
       }
     }
   }
+all_done:
 
-  if (stats && lane == 0) {
+  if (STATS && lane == 0) {
     atomicAdd(stats + 0, (unsigned long long)st_visited);
     atomicAdd(stats + 1, (unsigned long long)st_culled);
     atomicAdd(stats + 2, (unsigned long long)st_lanes);
@@ -802,9 +803,14 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
   const int T = gx * gy;
   const int split = ctx->opt[GGD_OPT_BLEND_SPLIT];   // 0: one wave per tile, 2: two (16x8), 3: four (8x8), 1: auto
   const int nsub = split == 0 ? 1 : (split == 2 ? 2 : 4);
+#define GGD_LAUNCH_FWD2(EM, CU, PX, BWID, ST)                                                                        \
+  hipLaunchKernelGGL((blend_forward_kernel<EM, CU, PX, BWID, ST>), dim3(nsub * T), dim3(64), 0, s, prm.width,          \
+                     prm.height, gx, T, splat, list, ranges, capacity, prm.bg, out_color, final_T, n_contrib,         \
+                     ctx->blend_stats)
 #define GGD_LAUNCH_FWD1(EM, CU, PX, BWID)                                                                            \
-  hipLaunchKernelGGL((blend_forward_kernel<EM, CU, PX, BWID>), dim3(nsub * T), dim3(64), 0, s, prm.width, prm.height, \
-                     gx, T, splat, list, ranges, capacity, prm.bg, out_color, final_T, n_contrib, ctx->blend_stats)
+  do {                                                                                                               \
+    if (ctx->blend_stats) GGD_LAUNCH_FWD2(EM, CU, PX, BWID, true); else GGD_LAUNCH_FWD2(EM, CU, PX, BWID, false);    \
+  } while (0)
 #define GGD_LAUNCH_FWD(EM, CU)                                                                                       \
   do {                                                                                                               \
     if (nsub == 4) GGD_LAUNCH_FWD1(EM, CU, 1, 8);                                                                    \
@@ -818,6 +824,7 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
   }
 #undef GGD_LAUNCH_FWD
 #undef GGD_LAUNCH_FWD1
+#undef GGD_LAUNCH_FWD2
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }
