@@ -554,20 +554,16 @@ __global__ __launch_bounds__(64) void blend_backward_kernel(
   }
 }
 
-// ---- backward blend, workgroup form: TWO waves per tile in ONE 128-thread workgroup -------------------------------------
-// Each wave owns a 16x8 half (2 pixels per lane: finer culling and fewer idle lanes than one wave per tile, half the
-// per-record pixel work), both walk the same 64-record rounds of the tile's list back to front, and their per-record
-// sums meet in LDS, so a (tile, Gaussian) pair still costs ONE float atomic per component.  The nine sums of a record
-// are reduced over the wave with a TRANSPOSED butterfly: eight of them enter as eight registers; a DPP step that adds
-// the partner lane's value is issued for the lanes (banks) that keep value A, then for the lanes that keep value B, into
-// the same register, so every step halves the registers (8 + 4 DPP adds down to two registers holding four values each,
-// one value per 4-lane bank), two full quad steps finish the 16-lane rows, and two lane-aligned xor-16 / xor-32 exchanges
-// fold the four rows: 16 DPP + 4 ds_bpermute + 4 adds instead of 48 DPP for eight values (the ninth takes the plain chain).
-// DPP reads of a just-written VGPR need 2 wait states: the independent chains are interleaved and padded with s_nop.
-__device__ __forceinline__ float wave_reduce8_transposed(float (&v)[8]) {
+// Nine wave sums with no LDS round trip: the eight of wave_reduce8_transposed plus a ninth that takes four all-lane DPP
+// steps inside its row, then rides in the redundant lanes of the first register (after the quad steps the four lanes of
+// a bank hold the same value; lane 4b + 1 of every bank is replaced by the ninth value's row sum).  The four rows are
+// folded with the gfx950 lane-block swaps: v_permlane32_swap(x0, x1) leaves {x0 rows 0,1 | x1 rows 0,1} and
+// {x0 rows 2,3 | x1 rows 2,3}, whose sum holds x0's values in lanes 0-31 and x1's in lanes 32-63 (two rows each);
+// v_permlane16_swap of that sum with a copy of itself pairs the remaining two rows.  Result per lane l:
+//   (l & 3) != 1:  value 4 * (l >> 5) + {0, 2, 1, 3}[(l >> 2) & 3]     l < 32 and (l & 3) == 1:  the ninth value
+__device__ __forceinline__ float wave_reduce9_swap(float (&v)[8], float ninth, uint64_t ninth_lanes /* 0x2222... */) {
   asm volatile(
       "s_nop 1\n\t"
-      // lanes l and l^8 of every row: banks 0,1 keep the even value of the pair, banks 2,3 the odd one
       "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
       "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
       "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
@@ -576,61 +572,77 @@ __device__ __forceinline__ float wave_reduce8_transposed(float (&v)[8]) {
       "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
       "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
       "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-      "s_nop 1\n\t"
-      // lanes l and l^4 inside each 8-lane half: banks 0,2 keep (v0|v1), (v4|v5); banks 1,3 take (v2|v3), (v6|v7)
+      "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
       "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
       "v_add_f32_dpp %4, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-      "s_nop 0\n\t"
+      "v_add_f32_dpp %8, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
       "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
       "v_add_f32_dpp %4, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
       "s_nop 1\n\t"
-      // the two remaining steps inside a 4-lane bank, all lanes
       "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
       "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
+      "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
       "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
       "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1"
-      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
-  // v[0]: banks 0..3 of every row = row totals of v0, v2, v1, v3; v[4] likewise for v4, v6, v5, v7.  Rows:
-  // (v_permlane32_swap / v_permlane16_swap through their builtins returned one row four times here; the two row steps go
-  // through the LDS crossbar instead: ds_bpermute, no LDS storage)
-  float x0 = v[0], x1 = v[4];
-  x0 += __shfl_xor(x0, 16, 64); x1 += __shfl_xor(x1, 16, 64);
-  x0 += __shfl_xor(x0, 32, 64); x1 += __shfl_xor(x1, 32, 64);
-  return (threadIdx.x & 32) ? x1 : x0;
-  // lane l (bank = (l >> 2) & 3) now holds the wave total of value 4 * (l >> 5) + {0, 2, 1, 3}[bank]: after the second
-  // step banks 0 / 2 carry the pair's first values (v0 | v1) and banks 1 / 3 the second (v2 | v3)
+      "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32_e64 %0, %0, %8, %9\n\t"
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %4\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_e32 %0, %0, %4\n\t"
+      "v_mov_b32_e32 %4, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %4\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_e32 %0, %0, %4"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(ninth)
+      : "s"(ninth_lanes));
+  return v[0];
 }
 
-template <int EXP_MODE, bool CULL>
-__global__ __launch_bounds__(128) void blend_backward_wg_kernel(
+// ---- backward blend, tile form: the waves of a tile in ONE workgroup, PXL pixels per lane ---------------------------
+// PXL = 1: four waves, each an 8x8 quarter (the forward's shape: finest culling, ~60 VGPRs -> 8 waves per SIMD, 16 k waves
+// for 4096 tiles); PXL = 2: two waves, each a 16x8 half.  Per round of 64 list entries every wave gathers the records
+// itself (the other waves' copies hit L2), pre-culls them against its own rectangle and stages the survivors; the NEXT
+// round's gather is issued before the current round is blended (the two dependent global loads of a round were the
+// largest stall of the first version).  Staged records are walked back to front in groups of 8 as straight-line
+// code (list padded with never-visible records, see the forward).  Per-record sums: transposed butterfly, parked in LDS
+// per wave, combined over the waves by the flush -> one float atomic per (tile, Gaussian, component).
+template <int EXP_MODE, bool CULL, int PXL>
+__global__ __launch_bounds__(256 / PXL) void blend_backward_tile_kernel(
     int W, int H, int gx, int gy, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ list,
     const uint32_t* __restrict__ ranges, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
-  __shared__ float4 s_rec[2][64 * 3];
-  __shared__ float s_sum[2][64][9];
-  __shared__ uint32_t s_id[64];
-  __shared__ float s_op[64];
-  __shared__ uint32_t s_touch[2][2];
-  __shared__ uint32_t s_maxn[2];
+  constexpr int NW = 4 / PXL;
+  __shared__ float4 s_rec[NW][64 * 3];
+  // per-round results are double-buffered: a round's flush reads buffer `par` while early waves already fill the other
+  // one, so a round costs ONE workgroup barrier (everybody finished the round), not two
+  __shared__ float s_sum[2][NW][64][9];
+  __shared__ uint32_t s_id[2][64];
+  __shared__ float s_op[2][64];
+  __shared__ uint32_t s_touch[2][NW][2];
+  __shared__ uint32_t s_maxn[NW];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int tile, sub_unused;
   ggd_block_to_tile((int)blockIdx.x, 1, gx, gy, gx * gy, tile, sub_unused);
   const int tx = tile % gx, ty = tile / gx;
-  const int px0 = tx * 16 + (lane & 7) * 2, py = ty * 16 + wv * 8 + (lane >> 3);
+  const int qx = PXL == 1 ? (wv & 1) : 0, qy = PXL == 1 ? (wv >> 1) : wv;
+  const int px0 = tx * 16 + qx * 8 + (lane & 7) * PXL, py = ty * 16 + qy * 8 + (lane >> 3);
   const uint2 rg = reinterpret_cast<const uint2*>(ranges)[tile];
   const bool row_in = py < H;
   const size_t HW = (size_t)H * W;
   const size_t pix0 = (size_t)py * W + px0;
 
-  float T[2], nTfin[2], la[2], bgdot[2], acc[2][3], lastc[2][3], gpx[2][3], px[2];
-  uint32_t lastn[2];
+  float T[PXL], nTfin[PXL], la[PXL], bgdot[PXL], acc[PXL][3], lastc[PXL][3], gpx[PXL][3], px[PXL];
+  uint32_t lastn[PXL];
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const float pyf = (float)py;
   uint32_t maxn = 0;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < PXL; ++k) {
     const bool in = row_in && (px0 + k) < W;
     const float tf = in ? final_T[pix0 + k] : 0.0f;
     lastn[k] = in ? n_contrib[pix0 + k] : 0u;
@@ -648,146 +660,161 @@ __global__ __launch_bounds__(128) void blend_backward_wg_kernel(
   for (int d = 32; d >= 1; d >>= 1) maxn = max(maxn, (uint32_t)__shfl_xor((int)maxn, d, 64));
   if (lane == 0) s_maxn[wv] = maxn;
   __syncthreads();
-  maxn = max(s_maxn[0], s_maxn[1]);   // workgroup-uniform: positions anyone in the tile contributed to
+  maxn = s_maxn[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) maxn = max(maxn, s_maxn[w]);   // workgroup-uniform: positions anyone in the tile contributed to
   if (maxn == 0) return;
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-  const float wx0 = (float)(tx * 16), wy0 = (float)(ty * 16 + wv * 8);   // this wave's 16 x 8 pixel rectangle
+  const float wx0 = (float)(tx * 16 + qx * 8), wy0 = (float)(ty * 16 + qy * 8);   // this wave's pixel rectangle
+  const float wx1 = wx0 + (float)(8 * PXL - 1), wy1 = wy0 + 7.0f;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   float4* rec = s_rec[wv];
+  const bool is_writer = (lane & 19) == 0 || lane == 1;
+  // reduction output index (colour r g b | conic A B C | mean x y | opacity) -> slot in the accumulator record's order
+  const int writer_val = lane == 1 ? 8 : 4 * (lane >> 5) + (((lane >> 2) & 1) << 1) + ((lane >> 3) & 1);
+  const int writer_comp = writer_val < 3 ? GGD_ACC_COLOR + writer_val
+                        : (writer_val < 6 ? GGD_ACC_CONIC + (writer_val - 3)
+                        : (writer_val < 8 ? GGD_ACC_MEAN2D + (writer_val - 6) : GGD_ACC_OPACITY));
+
+  // staged: {x, y, hA, nB} {hC, power threshold, opacity, 0-based list position} {r, g, b, index inside the round}
+  float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
+  bool keep = false;
+  uint32_t my_id = 0;
+  auto gather = [&](uint32_t ce) {   // the round that ends at list position ce (exclusive)
+    keep = false;
+    if (ce <= rg.x) return;
+    const uint32_t cs = (ce - rg.x > 64u) ? ce - 64u : rg.x;
+    if ((uint32_t)lane < ce - cs) {
+      my_id = list[cs + lane];
+      const float4* p = reinterpret_cast<const float4*>(splat + my_id);
+      const float4 r0 = p[0], r1 = p[1], r2 = p[2];   // x y hA nB | hC thr opacity r | g b ex ey
+      q0 = r0;
+      q1 = make_float4(r1.x, CULL ? r1.y : -__builtin_huge_valf(), r1.z, __uint_as_float((cs - rg.x) + (uint32_t)lane));
+      q2 = make_float4(r1.w, r2.x, r2.y, __uint_as_float((uint32_t)lane));
+      keep = CULL ? (record_box_hits(r0.x, r0.y, r2.z, r2.w, wx0, wx1, wy0, wy1) &&
+                     record_reaches_block(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, wx0, wx1, wy0, wy1)) : true;
+    }
+  };
 
   uint32_t cend = rg.x + maxn;  // one past the last position that matters
+  gather(cend);
+  int par = 0;
   while (cend > rg.x) {
     const uint32_t cstart = (cend - rg.x > 64u) ? cend - 64u : rg.x;
     const int n = (int)(cend - cstart);
-    __syncthreads();            // the previous round's flush has read s_sum / s_touch / s_id
-    bool keep = false;
-    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
-    if (lane < n) {
-      const uint32_t my_id = list[cstart + lane];
-      const float4* p = reinterpret_cast<const float4*>(splat + my_id);
-      const float4 r0 = p[0], r1 = p[1], r2 = p[2];   // x y hA nB | hC thr opacity r | g b ex ey
-      // staged: {x, y, hA, nB} {hC, power threshold, opacity, 0-based list position} {r, g, b, index inside the round}
-      q0 = r0;
-      q1 = make_float4(r1.x, CULL ? r1.y : -__builtin_huge_valf(), r1.z, __uint_as_float((cstart - rg.x) + (uint32_t)lane));
-      q2 = make_float4(r1.w, r2.x, r2.y, __uint_as_float((uint32_t)lane));
-      keep = CULL ? (record_box_hits(r0.x, r0.y, r2.z, r2.w, wx0, wx0 + 15.0f, wy0, wy0 + 7.0f) &&
-                     record_reaches_block(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, wx0, wx0 + 15.0f, wy0, wy0 + 7.0f)) : true;
-      if (wv == 0) { s_id[lane] = my_id; s_op[lane] = r1.z; }
-    }
     const uint64_t kept = __ballot(keep);
-    const int nk = __popcll(kept);
+    const int nk = __popcll(kept), n8 = (nk + 7) & ~7;
     if (keep) {  // compacted, order preserved
       const int slot = __popcll(kept & lt_mask);
       rec[slot * 3 + 0] = q0; rec[slot * 3 + 1] = q1; rec[slot * 3 + 2] = q2;
     }
+    if (lane >= nk && lane < n8) {   // padding: a record nobody sees
+      rec[lane * 3 + 0] = make_float4(0, 0, 0, 0);
+      rec[lane * 3 + 1] = make_float4(0, __builtin_huge_valf(), 0, 0);
+    }
+    if (wv == 0 && lane < n) { s_id[par][lane] = my_id; s_op[par][lane] = q1.z; }
+    gather(cstart);             // next round's records are in flight while this round is blended
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     uint64_t touched = 0ull;
-    // search-then-update (see the forward): the inner loop only looks for the next record some pixel of the wave saw
-    int j = nk - 1;
-    while (true) {
-      float4 a, b, c;
-      float dx[2], pw[2];
-      uint64_t need[2];
-      bool found = false;
-      while (j >= 0) {
-        a = rec[j * 3 + 0]; b = rec[j * 3 + 1]; c = rec[j * 3 + 2];
-        --j;
+    for (int j0 = n8 - 8; j0 >= 0; j0 -= 8) {
+      const float4* grp = rec + j0 * 3;
+#pragma unroll
+      for (int jj = 7; jj >= 0; --jj) {
+        const float4 a = grp[jj * 3 + 0], b = grp[jj * 3 + 1];
         const float dy = a.y - pyf;
         const float nBdy = a.w * dy, hCdy2 = (b.x * dy) * dy;
         const uint32_t pos0 = __float_as_uint(b.w);
-        uint64_t any = 0ull;
+        float dx[PXL], pw[PXL];
+        uint64_t need[PXL], any = 0ull;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < PXL; ++k) {
           dx[k] = a.x - px[k];
           pw[k] = __builtin_fmaf(__builtin_fmaf(a.z, dx[k], nBdy), dx[k], hCdy2);
-          need[k] = __ballot((pos0 < lastn[k]) && (pw[k] >= b.y));
+          need[k] = __ballot(pos0 < lastn[k]) & __ballot(pw[k] >= b.y);   // two compares into SGPR pairs + s_and
           any |= need[k];
         }
-        if (any != 0ull) { found = true; break; }
-      }
-      if (!found) break;
-      const float dy = a.y - pyf;
-      const float cA = -2.0f * a.z, cB = -a.w, cC = -2.0f * b.x;   // the conic (exact rescalings of hA, nB, hC)
-      const float col[3] = {c.x, c.y, c.z};
-      float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sop = 0.0f;   // colour r g b | conic A B C | mean x y ; opacity
-      uint64_t any_live = 0ull;
+        if (any == 0ull) continue;
+        const float4 c = grp[jj * 3 + 2];
+        const float cA = -2.0f * a.z, cB = -a.w, cC = -2.0f * b.x;   // the conic (exact rescalings of hA, nB, hC)
+        const float col[3] = {c.x, c.y, c.z};
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sop = 0.0f;   // colour r g b | conic A B C | mean x y ; opacity
+        uint64_t any_live = 0ull;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        // exact per-pixel visibility test, then alpha = G = 0 for pixels that do not see the record: every state update
-        // below is then an exact no-op for them (select-free recurrences)
-        const float g0 = blend_exp<EXP_MODE>(pw[k]);
-        const float a0 = fminf(0.99f, b.z * g0);
-        const uint64_t live = need[k] & ~__ballot(pw[k] > 0.0f) & ~__ballot(a0 < ALPHA_FLOOR);
-        any_live |= live;
-        const float G = sel_or_zero(g0, live), alpha = sel_or_zero(a0, live);
-        const float om = 1.0f - alpha;
-        float inv = __builtin_amdgcn_rcpf(om);
-        inv = __builtin_fmaf(inv, __builtin_fmaf(-om, inv, 1.0f), inv);
-        T[k] = T[k] * inv;
-        const float dchannel_dcolor = alpha * T[k];
-        const float oml = 1.0f - la[k];
-        float dL_dalpha = 0.0f;
+        for (int k = 0; k < PXL; ++k) {
+          // exact per-pixel visibility test, then alpha = G = 0 for pixels that do not see the record: every state
+          // update below is then an exact no-op for them (select-free recurrences)
+          const float g0 = blend_exp<EXP_MODE>(pw[k]);
+          const float a0 = fminf(0.99f, b.z * g0);
+          const uint64_t live = need[k] & ~__ballot(pw[k] > 0.0f) & ~__ballot(a0 < ALPHA_FLOOR);
+          any_live |= live;
+          const float G = sel_or_zero(g0, live), alpha = sel_or_zero(a0, live);
+          const float om = 1.0f - alpha;
+          float inv = __builtin_amdgcn_rcpf(om);
+          inv = __builtin_fmaf(inv, __builtin_fmaf(-om, inv, 1.0f), inv);
+          T[k] = T[k] * inv;
+          const float dchannel_dcolor = alpha * T[k];
+          const float oml = 1.0f - la[k];
+          float dL_dalpha = 0.0f;
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          acc[k][ch] = __builtin_fmaf(la[k], lastc[k][ch], oml * acc[k][ch]);
-          lastc[k][ch] = col[ch];
-          dL_dalpha = __builtin_fmaf(col[ch] - acc[k][ch], gpx[k][ch], dL_dalpha);
-          s[ch] = __builtin_fmaf(dchannel_dcolor, gpx[k][ch], s[ch]);
+          for (int ch = 0; ch < 3; ++ch) {
+            acc[k][ch] = __builtin_fmaf(la[k], lastc[k][ch], oml * acc[k][ch]);
+            asm volatile("v_mov_b32_e32 %0, %1" : "+v"(lastc[k][ch]) : "v"(col[ch]));   // in place (no copy on the culled path)
+            dL_dalpha = __builtin_fmaf(col[ch] - acc[k][ch], gpx[k][ch], dL_dalpha);
+            s[ch] = __builtin_fmaf(dchannel_dcolor, gpx[k][ch], s[ch]);
+          }
+          la[k] = alpha;
+          dL_dalpha = __builtin_fmaf(nTfin[k] * inv, bgdot[k], dL_dalpha * T[k]);
+          const float gdx = G * dx[k], gdy = G * dy;
+          const float ex = __builtin_fmaf(gdy, cB, gdx * cA);   // -dG/d(delta x)
+          const float ey = __builtin_fmaf(gdx, cB, gdy * cC);   // -dG/d(delta y)
+          s[6] = __builtin_fmaf(dL_dalpha, ex, s[6]);
+          s[7] = __builtin_fmaf(dL_dalpha, ey, s[7]);
+          const float wx = gdx * dL_dalpha, wy = gdy * dL_dalpha;
+          s[3] = __builtin_fmaf(wx, dx[k], s[3]);
+          s[4] = __builtin_fmaf(wx, dy, s[4]);
+          s[5] = __builtin_fmaf(wy, dy, s[5]);
+          sop = __builtin_fmaf(G, dL_dalpha, sop);
         }
-        la[k] = alpha;
-        dL_dalpha = __builtin_fmaf(nTfin[k] * inv, bgdot[k], dL_dalpha * T[k]);
-        const float gdx = G * dx[k], gdy = G * dy;
-        const float ex = __builtin_fmaf(gdy, cB, gdx * cA);   // -dG/d(delta x)
-        const float ey = __builtin_fmaf(gdx, cB, gdy * cC);   // -dG/d(delta y)
-        s[6] = __builtin_fmaf(dL_dalpha, ex, s[6]);
-        s[7] = __builtin_fmaf(dL_dalpha, ey, s[7]);
-        const float wx = gdx * dL_dalpha, wy = gdy * dL_dalpha;
-        s[3] = __builtin_fmaf(wx, dx[k], s[3]);
-        s[4] = __builtin_fmaf(wx, dy, s[4]);
-        s[5] = __builtin_fmaf(wy, dy, s[5]);
-        sop = __builtin_fmaf(G, dL_dalpha, sop);
-      }
-      if (any_live != 0ull) {   // wave-uniform: somebody in this half saw the Gaussian
-        const uint32_t ridx = __float_as_uint(c.w);
-        touched |= 1ull << ridx;
-        const float tot = wave_reduce8_transposed(s);
-        const float top = ggd_wave_sum_to63(sop);
-        float* o = &s_sum[wv][ridx][0];
-        if ((lane & 19) == 0) o[4 * (lane >> 5) + (((lane >> 2) & 1) << 1) + ((lane >> 3) & 1)] = tot;   // lanes 0,4,8,12 | 32,36,40,44
-        if (lane == 63) o[8] = top;
+        if (any_live != 0ull) {   // wave-uniform: somebody in this wave saw the Gaussian
+          const uint32_t ridx = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(c.w));
+          touched |= 1ull << ridx;
+          const float tot = wave_reduce9_swap(s, sop, 0x2222222222222222ull);
+          // writers: lanes 0,4,8,12 | 32,36,40,44 (component from the table above), lane 1 the opacity sum
+          if (is_writer) s_sum[par][wv][ridx][writer_comp] = tot;
+        }
       }
     }
-    if (lane == 0) { s_touch[wv][0] = (uint32_t)touched; s_touch[wv][1] = (uint32_t)(touched >> 32); }
+    if (lane == 0) { s_touch[par][wv][0] = (uint32_t)touched; s_touch[par][wv][1] = (uint32_t)(touched >> 32); }
     __syncthreads();
     {
-      // flush: thread (wave w, lane r) adds components [5w, 5w + 5) of record r of the round: both halves' sums, the
-      // per-record constants (opacity, -1/2, the 0.5 W / 0.5 H of the pixel-to-NDC map), one atomic per component
-      const uint64_t t0 = (uint64_t)s_touch[0][0] | ((uint64_t)s_touch[0][1] << 32);
-      const uint64_t t1 = (uint64_t)s_touch[1][0] | ((uint64_t)s_touch[1][1] << 32);
-      const bool h0 = (t0 >> lane) & 1ull, h1 = (t1 >> lane) & 1ull;
-      if (lane < n && (h0 || h1)) {
-        const float op = s_op[lane];
-        float* g = grad_acc + GGD_ACC_FLOATS * (size_t)s_id[lane];
-        const float nho = -0.5f * op;   // d alpha / d G = opacity; d G / d conic = -1/2 G d d^T
+      // flush: the round's (record, component) sums over the workgroup's threads, component fastest -- s_sum keeps the
+      // accumulator record's order (conic A B C | opacity | mean x y | colour r g b), so consecutive lanes add to
+      // consecutive floats of one 48-byte record and the atomics of a record reach L2 as one or two requests
+      // instead of nine (a lane per record and one component per instruction was bound by the L2 atomic units).
+      // All waves' sums and the per-record constants (opacity, -1/2, the 0.5 W / 0.5 H of the pixel-to-NDC map) are applied here.
+      uint64_t tw[NW];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-          const int comp = 5 * wv + q;
-          if (comp < 9) {
-            const float v = (h0 ? s_sum[0][lane][comp] : 0.0f) + (h1 ? s_sum[1][lane][comp] : 0.0f);
-#ifdef GGD_BWD_NO_ATOMICS   /* timing experiment only: plain stores instead of the atomics (wrong sums) */
-            g[comp] = v; continue;
-#endif
-            if (comp < 3) atomicAdd(g + GGD_ACC_COLOR + comp, v);
-            else if (comp < 6) atomicAdd(g + GGD_ACC_CONIC + (comp - 3), nho * v);
-            else if (comp == 6) atomicAdd(g + GGD_ACC_MEAN2D + 0, (-op * ddelx_dx) * v);
-            else if (comp == 7) atomicAdd(g + GGD_ACC_MEAN2D + 1, (-op * ddely_dy) * v);
-            else atomicAdd(g + GGD_ACC_OPACITY, v);
-          }
+      for (int w = 0; w < NW; ++w) tw[w] = (uint64_t)s_touch[par][w][0] | ((uint64_t)s_touch[par][w][1] << 32);
+      for (int t = threadIdx.x; t < 64 * 9; t += 64 * NW) {
+        const int r = t / 9, slot = t - 9 * r;
+        if (r >= n) break;
+        float v = 0.0f;
+        bool hany = false;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const bool h = (tw[w] >> r) & 1ull;
+          hany = hany || h;
+          v += h ? (&s_sum[par][w][0][0])[t] : 0.0f;
         }
+        if (!hany) continue;
+        const float op = s_op[par][r];
+        const float scale = slot < 3 ? -0.5f * op : (slot == 4 ? -op * ddelx_dx : (slot == 5 ? -op * ddely_dy : 1.0f));
+        atomicAdd(grad_acc + GGD_ACC_FLOATS * (size_t)s_id[par][r] + slot, slot < 3 || slot == 4 || slot == 5 ? scale * v : v);
       }
     }
     cend = cstart;
+    par ^= 1;
   }
 }
 
@@ -836,34 +863,32 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
   if (gx * gy == 0) return GGD_OK;
   const int em = ctx->opt[GGD_OPT_EXP_MODE];
   const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
-  // two waves per tile (16x8 halves) when there are too few tiles to give every SIMD a couple of waves
   const int T = gx * gy;
   const int split = ctx->opt[GGD_OPT_BLEND_SPLIT];
-  // 1 (auto) / 3: two waves per tile in one workgroup, sums combined in LDS (blend_backward_wg_kernel);
-  // 0: one wave per tile (4 px / lane); 2: two independent waves per tile (atomics per half)
-  if (split == 1 || split == 3) {
-#define GGD_LAUNCH_BWG(EM, CU)                                                                                          \
-    hipLaunchKernelGGL((blend_backward_wg_kernel<EM, CU>), dim3(T), dim3(128), 0, s, prm.width, prm.height, gx, gy, splat, \
-                       list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc)
+  // 1 (auto) / 3: four 8x8 waves per tile in one workgroup; 2: two 16x8 waves per tile in one workgroup (per-record sums
+  // combined in LDS: blend_backward_tile_kernel); 0: one wave per tile, 4 pixels per lane (blend_backward_kernel)
+  if (split != 0) {
+#define GGD_LAUNCH_BT(EM, CU)                                                                                             \
+    do {                                                                                                                  \
+      if (split != 2)                                                                                                     \
+        hipLaunchKernelGGL((blend_backward_tile_kernel<EM, CU, 1>), dim3(T), dim3(256), 0, s, prm.width, prm.height, gx,  \
+                           gy, splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc);                       \
+      else                                                                                                                \
+        hipLaunchKernelGGL((blend_backward_tile_kernel<EM, CU, 2>), dim3(T), dim3(128), 0, s, prm.width, prm.height, gx,  \
+                           gy, splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc);                       \
+    } while (0)
     if (cull) {
-      if (em == 0) GGD_LAUNCH_BWG(0, true); else if (em == 1) GGD_LAUNCH_BWG(1, true); else GGD_LAUNCH_BWG(2, true);
+      if (em == 0) GGD_LAUNCH_BT(0, true); else if (em == 1) GGD_LAUNCH_BT(1, true); else GGD_LAUNCH_BT(2, true);
     } else {
-      if (em == 0) GGD_LAUNCH_BWG(0, false); else if (em == 1) GGD_LAUNCH_BWG(1, false); else GGD_LAUNCH_BWG(2, false);
+      if (em == 0) GGD_LAUNCH_BT(0, false); else if (em == 1) GGD_LAUNCH_BT(1, false); else GGD_LAUNCH_BT(2, false);
     }
-#undef GGD_LAUNCH_BWG
+#undef GGD_LAUNCH_BT
     GGD_HIP(hipGetLastError());
     return GGD_OK;
   }
-  const bool two = split == 2;
 #define GGD_LAUNCH_BWD(EM, CU)                                                                                          \
-  do {                                                                                                                  \
-    if (two)                                                                                                            \
-      hipLaunchKernelGGL((blend_backward_kernel<EM, CU, 2>), dim3(2 * T), dim3(64), 0, s, prm.width, prm.height, gx, T, \
-                         splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc);                           \
-    else                                                                                                                \
-      hipLaunchKernelGGL((blend_backward_kernel<EM, CU, 4>), dim3(T), dim3(64), 0, s, prm.width, prm.height, gx, T,     \
-                         splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc);                           \
-  } while (0)
+  hipLaunchKernelGGL((blend_backward_kernel<EM, CU, 4>), dim3(T), dim3(64), 0, s, prm.width, prm.height, gx, T, splat,  \
+                     list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc)
   if (cull) {
     if (em == 0) GGD_LAUNCH_BWD(0, true); else if (em == 1) GGD_LAUNCH_BWD(1, true); else GGD_LAUNCH_BWD(2, true);
   } else {

@@ -67,6 +67,31 @@ def test_backward_matches_oracle(native_lib, case):
         assert (nb["dL_dsh"].reshape(d["P"], -1, 3)[:, used:] == 0).all()   # coefficients above the active degree
 
 
+@pytest.mark.parametrize("split", [0, 2, 3])
+@pytest.mark.parametrize("case", [dict(P=20000, size=256, kind="shell", lsm=-5.5), dict(P=4096, size=100, lsm=-5.0, width=100, height=52)],
+                         ids=_ids)
+def test_backward_kernel_forms_match_oracle(native_lib, case, split):
+    """Every form of the backward blend (GGD_OPT_BLEND_SPLIT: one wave per tile / two 16x8 waves / four 8x8 waves in one
+    workgroup) against the same reference and budget; the default (auto) is what the other tests run."""
+    import torch as _t
+    from gaussian_gan_decoder_amd import _capi
+    cx = _capi.context_for(_t.device("cuda:0"))
+    saved = cx.get_option(_capi.OPT_BLEND_SPLIT)
+    try:
+        cx.set_option(_capi.OPT_BLEND_SPLIT, split)
+        d = scene_inputs(**case)
+        g = make_dL_dpix(max(d["W"], d["H"]))[:, :d["H"], :d["W"]].contiguous()
+        o = run_oracle(d)
+        n = run_native(d, debug=False)
+        ref, budget, fragile = backward_reference(d, o, n, g.numpy())
+        nb = run_native_backward(d, n, g)
+        report = []
+        worst = check_gradients(d, nb, ref, budget, fragile, report=report)
+        assert worst <= 1.0, (split, report)
+    finally:
+        cx.set_option(_capi.OPT_BLEND_SPLIT, saved)
+
+
 def test_autograd_api_matches_oracle(native_lib):
     """Through GaussianRasterizer / render_simple exactly as the reference's train step does
     (main/train_pano2gaussian_decoder.py:223-232,263): activations in torch, grads on the RAW attributes.  Same
