@@ -201,10 +201,16 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, int W, int H, con
 // "Onesweep" LSD radix sort: ONE kernel per 8-bit digit pass (+ one up-front kernel that histograms every digit).
 //   * global digit histograms are permutation-invariant, so all passes' bin bases come from one read of the keys;
 //   * inside a pass every 4096-pair tile computes its digit counts, publishes them, and obtains the sum over all
-//     EARLIER tiles by decoupled look-back: a 32-bit status word per (tile, digit) = 2 flag bits | 30-bit count,
-//     written/read as single agent-scope relaxed atomics (the value IS the flag, so no fence is needed and the
-//     protocol is placement independent: per-XCD L2s are not coherent, agent-scope atomics bypass them);
-//     tiles take their index from an atomic ticket, so a tile only ever waits for tiles that are already running;
+//     EARLIER tiles from a fixed two-level tree: tiles form groups of G = 2^gshift (G ~ sqrt(#tiles)); the last tile
+//     of a group sums the group's counts and publishes the group aggregate; a tile then adds the aggregates of the
+//     earlier groups and the counts of the earlier tiles of its own group -- at most 2G independent loads, three
+//     dependent memory round trips per pass.  (The classic decoupled look-back chain needs ~#tiles / 16 dependent
+//     round trips here: all tiles of a pass start together, so nobody finds an inclusive prefix nearby -- 15 round
+//     trips and 7.5 M uncached status loads per pass at 245 tiles, the 14 us floor the passes used to have.)
+//     A status word per (tile | group, digit) = flag bit | 30-bit count, written / read as single agent-scope relaxed
+//     atomics (the value IS the flag, so no fence is needed and the protocol is placement independent: per-XCD L2s
+//     are not coherent, agent-scope atomics bypass them); tiles take their index from an atomic ticket and only ever
+//     wait for lower-numbered tiles, i.e. for tiles that are already running;
 //   * stability: element order inside a tile = (wave, round, lane); rank inside a wave by ballot matching.
 constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 16;                      // keys per lane
@@ -213,8 +219,15 @@ constexpr int RS_BINS = 256;
 constexpr int RS_MAX_PASSES = 8;
 constexpr int RS32_ITEMS = 16;                   // tile size of the 32-bit (depth) sort (4 was slower: longer look-back)
 constexpr int RS32_TILE = RS_THREADS * RS32_ITEMS;
-constexpr int RS_LOOKBACK = 8;   // predecessors examined per round trip of the decoupled look-back
-constexpr uint32_t RS_FLAG_LOCAL = 1u << 30, RS_FLAG_INCL = 2u << 30, RS_COUNT_MASK = (1u << 30) - 1u;
+constexpr int RS_HWORDS = RS_MAX_PASSES * RS_BINS;
+constexpr int RS_RESIDENT = 1024;   // tiles (256-thread workgroups, 5 KB LDS) that are certainly resident together on 256 CUs
+constexpr int RS_BATCH = 16;     // status words requested together while summing predecessors (batches are dependent round trips)
+constexpr uint32_t RS_FLAG = 1u << 30, RS_COUNT_MASK = (1u << 30) - 1u;
+// tiles per group of the two-level prefix: the power of two nearest to sqrt(ntiles) from above
+static inline int rs_gshift(int64_t ntiles) { int g = 2; while (((int64_t)1 << (2 * g)) < ntiles) ++g; return g; }
+static inline int64_t rs_status_words(int64_t ntiles) {   // per pass: tile words, then group words
+  return (ntiles + (ntiles >> rs_gshift(ntiles)) + 1) * RS_BINS;
+}
 
 __device__ __forceinline__ uint32_t rs_load(uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -280,17 +293,26 @@ template <typename KeyT, bool IOTA, int ITEMS, bool COMPACT = false>
 __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
     const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int64_t n_host, int shift, const uint32_t* __restrict__ ghist /*[256] of this pass*/,
-    uint32_t* status /*[ntiles][256]*/, uint32_t* ticket, const uint32_t* __restrict__ n_dev = nullptr) {
-  const int64_t n = (COMPACT && !IOTA) ? (int64_t)*n_dev : n_host;
+    uint32_t* status /*[ntiles + groups][256]*/, int ntiles, int gshift, uint32_t* ticket,
+    const uint32_t* __restrict__ n_dev = nullptr) {
   __shared__ uint32_t s_cnt[4][RS_BINS];   // per-wave running digit counts -> per-wave scatter bases
   __shared__ uint32_t s_scan[4];
   __shared__ uint32_t s_tile;
+  __shared__ uint32_t s_flat;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  // A pass is a chain of dependent memory round trips (1-2 us each, one workgroup per CU, nothing to overlap them with):
+  // everything that does not depend on anything else is requested up front -- the element count, this thread's bin
+  // of the global histogram, and the tile's keys / values (bounded by the host's n; masked by the device's n later).
+  // With all tiles resident at once (ntiles <= RS_RESIDENT) the tile index is blockIdx.x -- workgroups are started in
+  // index order and nobody is ever descheduled, so waiting on lower indices cannot deadlock; beyond that the ticket.
+  const bool use_ticket = ntiles > RS_RESIDENT;
+  if (use_ticket && threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  const uint32_t n_dev_v = (COMPACT && !IOTA) ? *n_dev : 0u;
+  const uint32_t my_bin = ghist[threadIdx.x];
   for (int b = threadIdx.x; b < 4 * RS_BINS; b += RS_THREADS) (&s_cnt[0][0])[b] = 0;
-  __syncthreads();
-  const uint32_t tile = s_tile;
-  if (COMPACT && (int64_t)tile * (RS_THREADS * ITEMS) >= n) return;   // beyond the kept elements (uniform per block)
+  if (threadIdx.x == 0) s_flat = 0u;
+  uint32_t tile = blockIdx.x;
+  if (use_ticket) { __syncthreads(); tile = s_tile; }
 
   const int64_t wbase = (int64_t)tile * (RS_THREADS * ITEMS) + (int64_t)wv * (64 * ITEMS);
   KeyT key[ITEMS];
@@ -299,14 +321,18 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const int64_t idx = wbase + r * 64 + lane;
-    const bool ok = idx < n;
+    const bool ok = idx < n_host;
     key[r] = ok ? keys_in[idx] : (KeyT)~(KeyT)0;
     val[r] = IOTA ? (uint32_t)idx : (ok ? vals_in[idx] : 0u);
   }
+  const int64_t n = (COMPACT && !IOTA) ? (int64_t)n_dev_v : n_host;
+  if (COMPACT && (int64_t)tile * (RS_THREADS * ITEMS) >= n) return;   // beyond the kept elements (uniform per block)
+  if (!use_ticket) __syncthreads();                                    // s_cnt / s_flat are zeroed
   if (COMPACT && !IOTA) {
-    // constant digit: the pass is the identity permutation
-    const uint32_t d0 = (uint32_t)(keys_in[0] >> shift) & 0xffu;
-    if ((int64_t)ghist[d0] == n) {
+    // constant digit (one bin of the pass's histogram holds every element): the pass is the identity permutation
+    if ((int64_t)my_bin == n) s_flat = 1u;
+    __syncthreads();
+    if (s_flat != 0u) {
 #pragma unroll
       for (int r = 0; r < ITEMS; ++r) {
         const int64_t idx = wbase + r * 64 + lane;
@@ -340,37 +366,40 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
     const int d = threadIdx.x;
     const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
     const uint32_t local = c0 + c1 + c2 + c3;
-    uint32_t* my = status + (size_t)tile * RS_BINS + d;
-    uint32_t excl = 0;
-    if (tile == 0) {
-      rs_store(my, RS_FLAG_INCL | local);
-    } else {
-      rs_store(my, RS_FLAG_LOCAL | local);
-      // look-back, 8 predecessors per round trip (independent loads in flight together)
-      int64_t t = (int64_t)tile - 1;
-      bool done = false;
-      while (!done) {
-        uint32_t v[RS_LOOKBACK];
+    // sum of `cnt` published words p[0], p[stride], ...: RS_BATCH requests in flight, unpublished ones are polled
+    auto sum_words = [&](uint32_t* p, int cnt) {
+      uint32_t acc = 0;
+      for (int b0 = 0; b0 < cnt; b0 += RS_BATCH) {
+        uint32_t v[RS_BATCH];
 #pragma unroll
-        for (int i = 0; i < RS_LOOKBACK; ++i) v[i] = (t - i >= 0) ? rs_load(status + (size_t)(t - i) * RS_BINS + d) : RS_FLAG_INCL;
+        for (int i = 0; i < RS_BATCH; ++i) v[i] = (b0 + i < cnt) ? rs_load(p + (size_t)(b0 + i) * RS_BINS) : RS_FLAG;
 #pragma unroll
-        for (int i = 0; i < RS_LOOKBACK; ++i) {
-          if (!done) {
-            uint32_t x = v[i];
-            if ((x >> 30) == 0u) {  // not published yet: poll this one
-              uint32_t* p = status + (size_t)(t - i) * RS_BINS + d;
-              do { __builtin_amdgcn_s_sleep(1); x = rs_load(p); } while ((x >> 30) == 0u);
-            }
-            excl += x & RS_COUNT_MASK;
-            if ((x >> 30) == 2u) done = true;
+        for (int i = 0; i < RS_BATCH; ++i) {
+          uint32_t x = v[i];
+          if ((x >> 30) == 0u) {
+            uint32_t* q = p + (size_t)(b0 + i) * RS_BINS;
+            do { __builtin_amdgcn_s_sleep(1); x = rs_load(q); } while ((x >> 30) == 0u);
           }
+          acc += x & RS_COUNT_MASK;
         }
-        t -= RS_LOOKBACK;
       }
-      rs_store(my, RS_FLAG_INCL | (excl + local));
-    }
+      return acc;
+    };
+    // group size from the number of tiles that hold elements (known on the device only in the compacting sort):
+    // G = 2^gshift ~ sqrt(live tiles), never above the launch's (the group words were laid out for that)
+    const int64_t live_tiles = (n + RS_THREADS * ITEMS - 1) / (RS_THREADS * ITEMS);
+    int gs = 2;
+    while (((int64_t)1 << (2 * gs)) < live_tiles) ++gs;
+    gshift = min(gshift, gs);
+    const int grp = (int)(tile >> gshift), mem = (int)(tile & ((1u << gshift) - 1u));
+    uint32_t* tile_words = status + d;                               // [tile][256]
+    uint32_t* group_words = status + (size_t)ntiles * RS_BINS + d;   // [group][256]
+    rs_store(tile_words + (size_t)tile * RS_BINS, RS_FLAG | local);
+    const uint32_t in_group = sum_words(tile_words + ((size_t)grp << gshift) * RS_BINS, mem);   // earlier tiles of my group
+    if (mem == (1 << gshift) - 1) rs_store(group_words + (size_t)grp * RS_BINS, RS_FLAG | (in_group + local));
+    const uint32_t excl = in_group + sum_words(group_words, grp);                              // earlier groups
     uint32_t tot;
-    const uint32_t gbase = block_exclusive_scan_256(ghist[d], &tot, s_scan);  // contains __syncthreads
+    const uint32_t gbase = block_exclusive_scan_256(my_bin, &tot, s_scan);  // contains __syncthreads
     const uint32_t base = gbase + excl;
     s_cnt[0][d] = base; s_cnt[1][d] = base + c0; s_cnt[2][d] = base + c0 + c1; s_cnt[3][d] = base + c0 + c1 + c2;
   }
@@ -430,15 +459,15 @@ static inline int sort_passes(int nbits) { return (nbits + 7) / 8; }
 int ggd_sort_input_is_alt(int nbits) { return sort_passes(nbits) & 1; }
 
 // tmp layout: [ghist: MAX_PASSES*256 u32][tickets: MAX_PASSES u32 (padded)][status: passes * ntiles * 256 u32]
-static inline size_t sort_ctrl_bytes() { return ggd_align((size_t)(RS_MAX_PASSES * RS_BINS + 64) * sizeof(uint32_t)); }
+static inline size_t sort_ctrl_bytes() { return ggd_align((size_t)(RS_HWORDS + 64) * sizeof(uint32_t)); }
 size_t ggd_sort_tmp_bytes(int64_t n) {
   const int64_t ntiles = (n + RS_TILE - 1) / RS_TILE;
-  return sort_ctrl_bytes() + ggd_align((size_t)RS_MAX_PASSES * (size_t)(ntiles > 0 ? ntiles : 1) * RS_BINS * sizeof(uint32_t));
+  return sort_ctrl_bytes() + ggd_align((size_t)RS_MAX_PASSES * (size_t)rs_status_words(ntiles > 0 ? ntiles : 1) * sizeof(uint32_t));
 }
 
 size_t ggd_sort32_tmp_bytes(int64_t n) {
   const int64_t ntiles = (n + RS32_TILE - 1) / RS32_TILE;
-  return sort_ctrl_bytes() + ggd_align((size_t)4 * (size_t)(ntiles > 0 ? ntiles : 1) * RS_BINS * sizeof(uint32_t));
+  return sort_ctrl_bytes() + ggd_align((size_t)4 * (size_t)rs_status_words(ntiles > 0 ? ntiles : 1) * sizeof(uint32_t));
 }
 
 template <typename KeyT>
@@ -450,9 +479,11 @@ static int launch_sort_t(ggd_ctx* ctx, hipStream_t s, KeyT* keys_a, uint32_t* va
   if (tmp_bytes < ggd_sort_tmp_bytes(n)) return ggd_fail(ctx, GGD_E_INVALID, "sort tmp too small");
   const int ntiles = (int)((n + RS_TILE - 1) / RS_TILE);
   uint32_t* ghist = static_cast<uint32_t*>(tmp);
-  uint32_t* tickets = ghist + RS_MAX_PASSES * RS_BINS;
+  uint32_t* tickets = ghist + RS_HWORDS;
   uint32_t* status = reinterpret_cast<uint32_t*>(static_cast<char*>(tmp) + sort_ctrl_bytes());
-  const size_t status_bytes = (size_t)passes * ntiles * RS_BINS * sizeof(uint32_t);
+  const size_t pass_words = (size_t)rs_status_words(ntiles);
+  const int gshift = rs_gshift(ntiles);
+  const size_t status_bytes = (size_t)passes * pass_words * sizeof(uint32_t);
   GGD_HIP(hipMemsetAsync(tmp, 0, sort_ctrl_bytes() + status_bytes, s));   // histograms, tickets, status words
   KeyT* kin = (passes & 1) ? keys_b : keys_a;
   uint32_t* vin = (passes & 1) ? vals_b : vals_a;
@@ -462,7 +493,7 @@ static int launch_sort_t(ggd_ctx* ctx, hipStream_t s, KeyT* keys_a, uint32_t* va
                      ghist);
   for (int p = 0; p < passes; ++p) {
     hipLaunchKernelGGL((sort_onesweep_kernel<KeyT, false, RS_ITEMS>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n,
-                       8 * p, ghist + p * RS_BINS, status + (size_t)p * ntiles * RS_BINS, tickets + p);
+                       8 * p, ghist + p * RS_BINS, status + (size_t)p * pass_words, ntiles, gshift, tickets + p);
     KeyT* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
   }
@@ -471,7 +502,7 @@ static int launch_sort_t(ggd_ctx* ctx, hipStream_t s, KeyT* keys_a, uint32_t* va
 }
 
 const uint32_t* ggd_sort32_nvalid_ptr(const void* tmp) {
-  return static_cast<const uint32_t*>(tmp) + RS_MAX_PASSES * RS_BINS + RS_MAX_PASSES;
+  return static_cast<const uint32_t*>(tmp) + RS_HWORDS + RS_MAX_PASSES;
 }
 
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
@@ -482,9 +513,11 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
   if (tmp_bytes < ggd_sort32_tmp_bytes(n)) return ggd_fail(ctx, GGD_E_INVALID, "sort tmp too small");
   const int ntiles = (int)((n + RS32_TILE - 1) / RS32_TILE);
   uint32_t* ghist = static_cast<uint32_t*>(tmp);
-  uint32_t* tickets = ghist + RS_MAX_PASSES * RS_BINS;
+  uint32_t* tickets = ghist + RS_HWORDS;
   uint32_t* status = reinterpret_cast<uint32_t*>(static_cast<char*>(tmp) + sort_ctrl_bytes());
-  const size_t status_bytes = (size_t)passes * ntiles * RS_BINS * sizeof(uint32_t);
+  const size_t pass_words = (size_t)rs_status_words(ntiles);
+  const int gshift = rs_gshift(ntiles);
+  const size_t status_bytes = (size_t)passes * pass_words * sizeof(uint32_t);
   GGD_HIP(hipMemsetAsync(tmp, 0, sort_ctrl_bytes() + status_bytes, s));
   // keys equal to 0xFFFFFFFF (culled Gaussians) are dropped by pass 0; n_valid (device) = number of kept keys, the
   // element count of every later pass and of the binning that consumes the order (word RS_MAX_PASSES of the tickets)
@@ -499,11 +532,11 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
     uint32_t* vout = (p & 1) ? vals_a : vals_b;
     if (p == 0)
       hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, true, RS32_ITEMS, true>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin,
-                         vin, kout, vout, n, 0, ghist, status, tickets, n_valid);
+                         vin, kout, vout, n, 0, ghist, status, ntiles, gshift, tickets, n_valid);
     else
       hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin,
-                         vin, kout, vout, n, 8 * p, ghist + p * RS_BINS, status + (size_t)p * ntiles * RS_BINS, tickets + p,
-                         n_valid);
+                         vin, kout, vout, n, 8 * p, ghist + p * RS_BINS, status + (size_t)p * pass_words, ntiles, gshift,
+                         tickets + p, n_valid);
     kin = kout; vin = vout;
   }
   GGD_HIP(hipGetLastError());
