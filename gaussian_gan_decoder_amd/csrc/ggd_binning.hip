@@ -69,9 +69,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
 }
 
 // One block turns block_sums[nb] into exclusive block prefixes (in place) and writes the grand total.
+// Rides along (one otherwise idle workgroup, an earlier launch of the same frame): the grand total also goes straight
+// into the pinned host mirror (h_total: no blit kernel for the num_rendered read-back), and `zero_words` words at
+// zero_ptr are cleared (the depth sort's histogram block: no memset launch in front of the sort).
 __global__ __launch_bounds__(SCAN_THREADS) void scan_blocksums_kernel(uint32_t* __restrict__ block_sums, int nb,
-                                                                      uint32_t* __restrict__ d_total) {
+                                                                      uint32_t* __restrict__ d_total,
+                                                                      uint32_t* h_total = nullptr,
+                                                                      uint32_t* __restrict__ zero_ptr = nullptr,
+                                                                      int zero_words = 0) {
   __shared__ uint32_t lds4[4];
+  for (int i = threadIdx.x; i < zero_words; i += SCAN_THREADS) zero_ptr[i] = 0u;
   uint32_t carry = 0;
   for (int start = 0; start < nb; start += SCAN_THREADS) {
     const int i = start + threadIdx.x;
@@ -82,6 +89,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_blocksums_kernel(uint32_t* 
     carry += tot;
   }
   if (threadIdx.x == 0 && d_total) *d_total = carry;
+  if (threadIdx.x == 0 && h_total) { *h_total = carry; __threadfence_system(); }
 }
 
 template <bool EXCLUSIVE>
@@ -122,16 +130,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
 
 template <bool EXCLUSIVE>
 int launch_scan(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, uint32_t* out, int64_t n, uint32_t* d_total,
-                void* tmp, size_t tmp_bytes) {
+                void* tmp, size_t tmp_bytes, uint32_t* h_total = nullptr, uint32_t* zero_ptr = nullptr,
+                int zero_words = 0) {
   if (n <= 0) {
     if (d_total) GGD_HIP(hipMemsetAsync(d_total, 0, sizeof(uint32_t), s));
+    if (h_total) *h_total = 0u;
+    if (zero_ptr && zero_words > 0) GGD_HIP(hipMemsetAsync(zero_ptr, 0, (size_t)zero_words * sizeof(uint32_t), s));
     return GGD_OK;
   }
   const int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
   if (tmp_bytes < (size_t)nb * sizeof(uint32_t)) return ggd_fail(ctx, GGD_E_INVALID, "scan tmp too small");
   uint32_t* block_sums = static_cast<uint32_t*>(tmp);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, block_sums);
-  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, block_sums, nb, d_total);
+  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, block_sums, nb, d_total, h_total, zero_ptr,
+                     zero_words);
   hipLaunchKernelGGL(scan_apply_kernel<EXCLUSIVE>, dim3(nb), dim3(SCAN_THREADS), 0, s, in, out, n, block_sums);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
@@ -243,8 +255,13 @@ __device__ __forceinline__ void rs_store(uint32_t* p, uint32_t v) {
 template <typename KeyT, int ITEMS, bool SKIP = false>
 __global__ __launch_bounds__(RS_THREADS) void sort_global_hist_kernel(const KeyT* __restrict__ keys, int64_t n,
                                                                       int passes, uint32_t* __restrict__ ghist,
-                                                                      uint32_t* __restrict__ n_valid = nullptr) {
+                                                                      uint32_t* __restrict__ n_valid = nullptr,
+                                                                      uint32_t* __restrict__ zero_ptr = nullptr,
+                                                                      size_t zero_words = 0) {
   __shared__ uint32_t s_hist[RS_MAX_PASSES * RS_BINS];
+  // the passes' status words are cleared here (every workgroup a slice) when the caller skipped the memset
+  for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < zero_words; i += (size_t)gridDim.x * RS_THREADS)
+    zero_ptr[i] = 0u;
   uint32_t my_valid = 0;
   for (int b = threadIdx.x; b < passes * RS_BINS; b += RS_THREADS) s_hist[b] = 0;
   __syncthreads();
@@ -446,6 +463,12 @@ int ggd_launch_inclusive_scan(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, u
   return launch_scan<false>(ctx, s, in, out, n, d_total, tmp, tmp_bytes);
 }
 
+int ggd_launch_inclusive_scan_ex(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, uint32_t* out, int64_t n,
+                                 uint32_t* d_total, void* tmp, size_t tmp_bytes, uint32_t* h_total, uint32_t* zero_ptr,
+                                 int zero_words) {
+  return launch_scan<false>(ctx, s, in, out, n, d_total, tmp, tmp_bytes, h_total, zero_ptr, zero_words);
+}
+
 int ggd_launch_duplicate(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect, const uint32_t* depth_keys,
                          const uint32_t* tiles_touched, const uint32_t* offsets, uint64_t* keys, uint32_t* vals) {
   if (prm.P == 0) return GGD_OK;
@@ -505,25 +528,32 @@ const uint32_t* ggd_sort32_nvalid_ptr(const void* tmp) {
   return static_cast<const uint32_t*>(tmp) + RS_HWORDS + RS_MAX_PASSES;
 }
 
+size_t ggd_sort_ctrl_words() { return sort_ctrl_bytes() / sizeof(uint32_t); }
+
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
-                           uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes) {
+                           uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
+                           uint32_t* clean_ctl) {
   if (n <= 0) return GGD_OK;
   const int passes = sort_passes(nbits);
   if (passes > RS_MAX_PASSES || (passes & 1)) return ggd_fail(ctx, GGD_E_INVALID, "sort32: need an even pass count");
   if (tmp_bytes < ggd_sort32_tmp_bytes(n)) return ggd_fail(ctx, GGD_E_INVALID, "sort tmp too small");
   const int ntiles = (int)((n + RS32_TILE - 1) / RS32_TILE);
-  uint32_t* ghist = static_cast<uint32_t*>(tmp);
+  // control block (histograms, tickets, n_valid): `clean_ctl` = a block an earlier kernel of this frame has already
+  // cleared (then the status words are cleared by the histogram kernel and the sort needs no memset launch), else the
+  // head of tmp
+  uint32_t* ghist = clean_ctl ? clean_ctl : static_cast<uint32_t*>(tmp);
   uint32_t* tickets = ghist + RS_HWORDS;
   uint32_t* status = reinterpret_cast<uint32_t*>(static_cast<char*>(tmp) + sort_ctrl_bytes());
   const size_t pass_words = (size_t)rs_status_words(ntiles);
   const int gshift = rs_gshift(ntiles);
   const size_t status_bytes = (size_t)passes * pass_words * sizeof(uint32_t);
-  GGD_HIP(hipMemsetAsync(tmp, 0, sort_ctrl_bytes() + status_bytes, s));
+  if (!clean_ctl) GGD_HIP(hipMemsetAsync(tmp, 0, sort_ctrl_bytes() + status_bytes, s));
   // keys equal to 0xFFFFFFFF (culled Gaussians) are dropped by pass 0; n_valid (device) = number of kept keys, the
   // element count of every later pass and of the binning that consumes the order (word RS_MAX_PASSES of the tickets)
   uint32_t* n_valid = tickets + RS_MAX_PASSES;
   hipLaunchKernelGGL((sort_global_hist_kernel<uint32_t, RS32_ITEMS, true>), dim3(ntiles), dim3(RS_THREADS), 0, s,
-                     keys_src, n, passes, ghist, n_valid);
+                     keys_src, n, passes, ghist, n_valid, clean_ctl ? status : nullptr,
+                     clean_ctl ? status_bytes / sizeof(uint32_t) : (size_t)0);
   // pass 0: keys_src (read-only, caller's buffer) -> B with identity values; then B -> A -> B -> A ...
   const uint32_t* kin = keys_src;
   const uint32_t* vin = nullptr;

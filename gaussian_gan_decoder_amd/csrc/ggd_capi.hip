@@ -116,6 +116,18 @@ extern "C" ggd_ctx* ggd_create(int device) {
             hipHostMalloc((void**)&ctx->h_words, 64, hipHostMallocDefault) == hipSuccess &&
             hipMemset(ctx->d_words, 0, 256) == hipSuccess;
   for (int i = 0; ok && i < 2 * ST_COUNT; ++i) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
+  // device-side view of the pinned mirror (the scan writes num_rendered there itself: no blit for the read-back) and the
+  // depth sort's control block in its own allocation (cleared by the scan: no memset launch in front of the sort);
+  // both are optional -- without them the forward falls back to the copy / the memset
+  if (ok && hipHostGetDevicePointer((void**)&ctx->h_words_dev, ctx->h_words, 0) != hipSuccess) {
+    ctx->h_words_dev = nullptr;
+    (void)hipGetLastError();
+  }
+  if (ok && (hipMalloc((void**)&ctx->sortctl, ggd_sort_ctrl_words() * sizeof(uint32_t)) != hipSuccess ||
+             hipMemset(ctx->sortctl, 0, ggd_sort_ctrl_words() * sizeof(uint32_t)) != hipSuccess)) {
+    ctx->sortctl = nullptr;
+    (void)hipGetLastError();
+  }
   (void)hipSetDevice(prev);
   if (!ok) {
     ggd_fail(nullptr, GGD_E_HIP, std::string("ggd_create: ") + hipGetErrorString(hipGetLastError()));
@@ -130,6 +142,7 @@ extern "C" void ggd_destroy(ggd_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->d_words) (void)hipFree(ctx->d_words);
   if (ctx->h_words) (void)hipHostFree(ctx->h_words);
+  if (ctx->sortctl) (void)hipFree(ctx->sortctl);
   if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);
   if (ctx->dbg_vals) (void)hipFree(ctx->dbg_vals);
   for (int i = 0; i < 2 * ST_COUNT; ++i)
@@ -255,12 +268,18 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
   }
   {
     StageTimer t(ctx, ST_SCAN, s);
-    rc = ggd_launch_inclusive_scan(ctx, s, tiles, offsets, prm->P, ctx->d_words, ctx->scratch, ctx->scratch_bytes);
+    rc = ggd_launch_inclusive_scan_ex(ctx, s, tiles, offsets, prm->P, ctx->d_words, ctx->scratch, ctx->scratch_bytes,
+                                      ctx->h_words_dev, ctx->sortctl, ctx->sortctl ? (int)ggd_sort_ctrl_words() : 0);
     if (rc != GGD_OK) return rc;
+    ctx->sortctl_clean = ctx->sortctl != nullptr;
   }
   {
     StageTimer t(ctx, ST_READBACK, s);
-    GGD_HIP(hipMemcpyAsync(ctx->h_words, ctx->d_words, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    // with the device view of the pinned mirror the scan has already delivered R; only the prefilter trap word is copied
+    if (!ctx->h_words_dev)
+      GGD_HIP(hipMemcpyAsync(ctx->h_words, ctx->d_words, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    else if (prm->prefiltered)
+      GGD_HIP(hipMemcpyAsync(ctx->h_words + 1, ctx->d_words + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   }
   return GGD_OK;
 }
@@ -340,15 +359,20 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
     uint32_t* vb = reinterpret_cast<uint32_t*>(sc + 3 * pairs);
     void* tmp = sc + 4 * pairs;
     void* bin_tmp_ptr = sc + 4 * pairs + sort_tmp;  // the sort's histogram block stays alive for the binning pass
+    uint32_t* clean_ctl = nullptr;
     {
       StageTimer t(ctx, ST_SORT, s);
-      rc = ggd_launch_sort32_iota(ctx, s, depth_keys, ka, va, kb, vb, prm->P, 32, tmp, sort_tmp);
+      // the control block this frame's scan cleared, if nobody has used it since (a second render of the same geometry
+      // falls back to the memset)
+      clean_ctl = ctx->sortctl_clean ? ctx->sortctl : nullptr;
+      ctx->sortctl_clean = false;
+      rc = ggd_launch_sort32_iota(ctx, s, depth_keys, ka, va, kb, vb, prm->P, 32, tmp, sort_tmp, clean_ctl);
       if (rc != GGD_OK) return rc;
     }
     {
       StageTimer t(ctx, ST_DUPLICATE, s);
       // the depth sort dropped the culled Gaussians (key 0xFFFFFFFF) and left the number of kept ones on the device
-      const uint32_t* n_vis = ggd_sort32_nvalid_ptr(tmp);
+      const uint32_t* n_vis = ggd_sort32_nvalid_ptr(clean_ctl ? static_cast<const void*>(clean_ctl) : tmp);
       rc = rowbin ? ggd_launch_rowbin(ctx, s, *prm, rect, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp)
                   : ggd_launch_tilebin(ctx, s, *prm, rect, tiles, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp);
       if (rc != GGD_OK) return rc;

@@ -30,6 +30,9 @@ struct ggd_ctx {
   uint32_t attr_mask = 0;       // GGD_ATTR_* bits: kernels whose dynamic-LDS limit was raised on this ctx's device
   uint32_t* d_words = nullptr;  // small device control block: [0] total R, [1] prefilter trap flag
   uint32_t* h_words = nullptr;  // pinned host mirror
+  uint32_t* h_words_dev = nullptr;  // the same memory as the device sees it (the scan writes num_rendered there itself)
+  uint32_t* sortctl = nullptr;      // depth sort's control block (histograms, tickets, kept-key count) in its own allocation
+  bool sortctl_clean = false;       // cleared by this frame's scan and not yet consumed by a sort
   void* dbg_keys = nullptr;     // debug copy of the unsorted list
   void* dbg_vals = nullptr;
   size_t dbg_cap = 0;
@@ -75,12 +78,17 @@ int ggd_launch_mark_visible(ggd_ctx* ctx, hipStream_t s, int P, const float* mea
 int ggd_launch_inclusive_scan(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, uint32_t* out, int64_t n,
                               uint32_t* d_total, void* tmp, size_t tmp_bytes);
 size_t ggd_scan_tmp_bytes(int64_t n);
+// same, plus: total also written to h_total (device view of a pinned host word) and zero_words words cleared at zero_ptr
+int ggd_launch_inclusive_scan_ex(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, uint32_t* out, int64_t n,
+                                 uint32_t* d_total, void* tmp, size_t tmp_bytes, uint32_t* h_total, uint32_t* zero_ptr,
+                                 int zero_words);
+size_t ggd_sort_ctrl_words();   // words of the depth sort's control block (ggd_launch_sort32_iota's clean_ctl)
 int ggd_launch_duplicate(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect,
                          const uint32_t* depth_keys, const uint32_t* tiles_touched, const uint32_t* offsets,
                          uint64_t* keys, uint32_t* vals);
 size_t ggd_sort_tmp_bytes(int64_t n);
 size_t ggd_sort32_tmp_bytes(int64_t n);
-const uint32_t* ggd_sort32_nvalid_ptr(const void* tmp);  // device word: keys kept by ggd_launch_sort32_iota
+const uint32_t* ggd_sort32_nvalid_ptr(const void* ctl);  // device word: keys kept by ggd_launch_sort32_iota (ctl = its control block: clean_ctl or tmp)
 // stable LSD radix sort of (key,val) pairs on key bits [0,nbits); result ends in (keys_a, vals_a); the input must
 // have been placed in the buffer ggd_sort_input_is_alt(nbits) says.
 int ggd_sort_input_is_alt(int nbits);
@@ -89,7 +97,8 @@ int ggd_launch_sort(ggd_ctx* ctx, hipStream_t s, uint64_t* keys_a, uint32_t* val
 // 32-bit-key variant (depth sort of the Gaussians).  keys_src is only read; the result ends in (keys_a, vals_a);
 // values start as the identity permutation.  nbits must be a multiple of 16 (even number of passes).
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
-                           uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes);
+                           uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
+                           uint32_t* clean_ctl = nullptr);
 // Tile binning (GGD_OPT_BINNING = 1): sorted Gaussian order -> per-tile lists + ranges.
 bool ggd_rowbin_supported(int W, int H);
 size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity);
