@@ -19,8 +19,8 @@ namespace {
 constexpr int RB_THREADS = 256;
 constexpr int RB_WAVES = RB_THREADS / 64;
 constexpr int RB_IPL = 4;                          // items per lane
-constexpr int RB_CHUNK = RB_THREADS * RB_IPL;      // 2048 items per workgroup
-constexpr int RB_WCHUNK = 64 * RB_IPL;             // 512 items per wave
+constexpr int RB_CHUNK = RB_THREADS * RB_IPL;      // 1024 items per workgroup
+constexpr int RB_WCHUNK = 64 * RB_IPL;             // 256 items per wave
 
 // tables (uint32): [0..64] row starts (65 entries, [64] = total entries), [65..129] first level-2 block of each row
 // (+ total), [130 .. 130 + 64*64) start of every (row, column) tile list
