@@ -140,3 +140,43 @@ def test_non_fp32_inputs_are_refused(native_lib):
                                            0, z(3), False, False)
     with pytest.raises(TypeError, match="float32"):
         dgr.GaussianRasterizer(rs)(z(4, 3).double(), z(4, 3), z(4, 1), shs=z(4, 1, 3), scales=z(4, 3), rotations=z(4, 4))
+
+
+def test_two_streams_render_concurrently(native_lib):
+    """Contexts are per (device, stream): two scenes rendered from two side streams at the same time (forward + backward,
+    no synchronisation between the streams) give exactly what each gives alone on the default stream."""
+    from _util import scene_inputs
+    from gaussian_gan_decoder_amd import rasterizer as R
+    dev = torch.device("cuda:0")
+
+    def args_of(d, leaf):
+        t = lambda x: torch.empty(0, device=dev) if x is None else x.to(dev)
+        return (t(d["bg"]), leaf, t(d["colors_precomp"]), t(d["opacities"]), t(d["scales"]), t(d["rotations"]),
+                d["scale_modifier"], t(d["cov3D_precomp"]), t(d["viewmatrix"]), t(d["projmatrix"]), d["tanfovx"],
+                d["tanfovy"], d["H"], d["W"], t(d["shs"]), d["sh_degree"], t(d["campos"]), False, False)
+
+    def run(d, stream):
+        leaf = d["means3D"].to(dev).clone().requires_grad_(True)
+        a = args_of(d, leaf)
+        with torch.cuda.stream(stream):
+            color, radii = R.rasterize_gaussians(a[1], torch.zeros_like(a[1]), a[14], a[2], a[3], a[4], a[5], a[7],
+                                                 R.GaussianRasterizationSettings(a[12], a[13], a[10], a[11], a[0], a[6],
+                                                                                 a[8], a[9], a[15], a[16], False, False))
+            (color * color).sum().backward()
+        return color, leaf
+
+    scenes = [scene_inputs(P=30000, size=256, seed=1), scene_inputs(P=20000, size=192, seed=2, kind="shell", lsm=-5.5)]
+    torch.cuda.synchronize(dev)
+    alone = []
+    for d in scenes:
+        c, leaf = run(d, torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        alone.append((c.detach().cpu(), leaf.grad.detach().cpu()))
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    for rep in range(3):
+        outs = [run(d, s) for d, s in zip(scenes, streams)]
+        torch.cuda.synchronize(dev)
+        for (c, leaf), (c0, g0) in zip(outs, alone):
+            assert torch.equal(c.detach().cpu(), c0)
+            # the backward's float atomics are unordered: same tolerance class as two runs on one stream
+            assert (leaf.grad.detach().cpu() - g0).abs().max() <= 1e-4 * max(1.0, float(g0.abs().max()))
