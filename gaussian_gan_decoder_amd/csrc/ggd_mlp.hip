@@ -114,6 +114,16 @@ __device__ __forceinline__ void gelu_pack(const f4 (&acc)[2][8], bf16x8 (&bout)[
 // so that a lane's two tiles of a block are 16 contiguous bytes and the four lanes of a point write 64 contiguous bytes
 // per instruction (the natural order gives 8-byte pieces, which lean on L2 write combining).  zbuf and dzbuf share the
 // layout; the weight-gradient kernel maps positions back to features when it writes dW / db.
+// HBM form of zbuf / dzbuf ("blocked Z layout"): per (head, layer) an array of 16-point blocks of 4 KB,
+//   block[k][g][j][8]   k = 32-feature block, g = lane group, j = point inside the block, 8 bf16 = the lane's tiles 2k, 2k+1
+// i.e. exactly the order in which a wave holds the data: the 64 lanes of ONE store / load instruction touch 1024
+// contiguous bytes (the point-major form gave 16 separate 64-byte segments per instruction, half cache lines).  The
+// weight-gradient kernel streams the same bytes linearly and only re-interprets a chunk's (point, position).
+__device__ __forceinline__ int64_t zpiece(int64_t pt, int k, int g) {
+  return (pt >> 4) * (16 * HID) + (int64_t)k * 512 + g * 128 + (pt & 15) * 8;
+}
+__device__ __forceinline__ size_t zlayer_elems(int N) { return (size_t)((N + 15) & ~15) * HID; }   // one (head, layer) plane
+
 __device__ __forceinline__ void store_z(__bf16* __restrict__ zl, const f4 (&acc)[2][8], int64_t p0, int64_t cend,
                                         int lane) {
   const int j = lane & 15, g = lane >> 4;
@@ -123,7 +133,7 @@ __device__ __forceinline__ void store_z(__bf16* __restrict__ zl, const f4 (&acc)
     if (pt >= cend) continue;
 #pragma unroll
     for (int k = 0; k < 4; ++k)   // Z layout (zpos): the lane's tiles 2k, 2k+1 as ONE 16-byte piece; 4 lanes = 64 B
-      *reinterpret_cast<bf16x8*>(zl + pt * HID + 32 * k + 8 * g) = pack8(acc[c][2 * k], acc[c][2 * k + 1]);
+      *reinterpret_cast<bf16x8*>(zl + zpiece(pt, k, g)) = pack8(acc[c][2 * k], acc[c][2 * k + 1]);
   }
 }
 
@@ -131,7 +141,7 @@ __device__ __forceinline__ void store_z(__bf16* __restrict__ zl, const f4 (&acc)
 // [11..13] xyz, [14..15] unused.  It doubles as the carrier of the earlier heads' outputs between heads: the "info"
 // vector a head sees is [position(3), attrs[0 .. n_extra)] with n_extra = 0, 3, 4, 8, 11.
 // STORE_Z (training): the fp32 pre-activations of the three hidden layers are kept (rounded to bf16) for the backward,
-// zbuf[head][layer][point][128], row-major so the weight-gradient GEMMs can read them as plain [N,128] matrices.
+// zbuf[head][layer][16-point block][4 KB] (blocked Z layout above).
 template <bool STORE_Z>
 __global__ __launch_bounds__(MLP_THREADS, 2) void decoder_forward_kernel(const float* __restrict__ feat,
                                                                          const float* __restrict__ pos, int N,
@@ -190,13 +200,13 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void decoder_forward_kernel(const f
       f4 acc[2][8];
       bf16x8 bh[2][4];
       layer_mfma<2, ROW1>(wl + OFF_W1, b1, bin, acc, lane);
-      if (STORE_Z) store_z(zbuf + ((size_t)(head * 3 + 0) * N) * HID, acc, p0, cend, lane);
+      if (STORE_Z) store_z(zbuf + (size_t)(head * 3 + 0) * zlayer_elems(N), acc, p0, cend, lane);
       gelu_pack(acc, bh);
       layer_mfma<4, ROW2>(wl + OFF_W2, b2, bh, acc, lane);
-      if (STORE_Z) store_z(zbuf + ((size_t)(head * 3 + 1) * N) * HID, acc, p0, cend, lane);
+      if (STORE_Z) store_z(zbuf + (size_t)(head * 3 + 1) * zlayer_elems(N), acc, p0, cend, lane);
       gelu_pack(acc, bh);
       layer_mfma<4, ROW2>(wl + OFF_W3, b3, bh, acc, lane);
-      if (STORE_Z) store_z(zbuf + ((size_t)(head * 3 + 2) * N) * HID, acc, p0, cend, lane);
+      if (STORE_Z) store_z(zbuf + (size_t)(head * 3 + 2) * zlayer_elems(N), acc, p0, cend, lane);
       gelu_pack(acc, bh);
       // ---- output layer: one feature tile (weight rows >= out_dim are zero)
       f4 out[2];
@@ -306,7 +316,9 @@ extern "C" int ggd_decoder_backward(ggd_ctx* ctx, void* stream, int32_t N, const
   return GGD_OK;
 }
 
-extern "C" size_t ggd_decoder_zbuf_bytes(int32_t N) { return (size_t)NHEAD * 3 * (size_t)(N > 0 ? N : 0) * HID * 2; }
+extern "C" size_t ggd_decoder_zbuf_bytes(int32_t N) {   // 16-point blocks: N rounded up to a multiple of 16
+  return (size_t)NHEAD * 3 * (size_t)(N > 0 ? ((N + 15) & ~15) : 0) * HID * 2;
+}
 
 extern "C" int ggd_decoder_forward_train(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
                                          const void* packed_weights, float* attrs, void* zbuf) {
