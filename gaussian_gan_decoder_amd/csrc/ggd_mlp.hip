@@ -36,6 +36,11 @@ constexpr int OFF_B = OFF_W4 + 16 * ROW2;          // fp32 biases: b1[128] b2[12
 constexpr int HEAD_BYTES = OFF_B + (3 * HID + 16) * 4;  // 94,784 B
 constexpr int MLP_THREADS = 512;
 constexpr int MLP_WAVES = MLP_THREADS / 64;
+// forward kernel: the waves that share one head's weights in LDS (95 KB: one workgroup per CU).  Measured at 1 M points:
+// 512 threads 0.796 ms, 768 (3 waves per SIMD, 150 VGPRs still fit) 0.787 ms, 1024 (128-VGPR cap: spills) 0.827 ms --
+// the kernel is not occupancy-bound.
+constexpr int FWD_THREADS = 512;
+constexpr int FWD_WAVES = FWD_THREADS / 64;
 constexpr int SLAB = 32;  // points per wave iteration (two 16-point MFMA column tiles share every weight read)
 
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -58,6 +63,29 @@ __device__ __forceinline__ f2v gelu2(f2v x) {
   p = __builtin_elementwise_fma(p, s2, (f2v){3.988329117e-01f, 3.988329117e-01f});
   const f2v phi = __builtin_elementwise_fma(xc, p, (f2v){0.5f, 0.5f});
   return x * phi;
+}
+
+// Four GELU pairs in lock step: the Horner recurrences of a packed polynomial are serial, and a v_pk_* op that reads the
+// result of the previous packed op needs a wait state (the compiler pads every step with s_nop 0: 800 of them per
+// slab and head) -- with four independent chains advanced together every dependent pair is four instructions apart
+// (904 -> 131 s_nop, 0.834 -> 0.806 ms at 1 M points).
+__device__ __forceinline__ void gelu2x4(f2v (&x)[4]) {
+  f2v xc[4], s2[4], p[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    xc[i] = (f2v){__builtin_amdgcn_fmed3f(x[i].x, -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x[i].y, -4.0f, 4.0f)};
+    s2[i] = xc[i] * xc[i];
+    p[i] = (f2v){-1.520480094e-09f, -1.520480094e-09f};
+  }
+  constexpr float C[7] = {1.180964698e-07f, -4.014221549e-06f, 7.960997496e-05f, -1.041295812e-03f,
+                          9.641715482e-03f, -6.614117560e-02f, 3.988329117e-01f};
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = __builtin_elementwise_fma(p[i], s2[i], (f2v){C[k], C[k]});
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = x[i] * __builtin_elementwise_fma(xc[i], p[i], (f2v){0.5f, 0.5f});
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f4& lo, const f4& hi) {
@@ -98,10 +126,10 @@ __device__ __forceinline__ void gelu_pack(const f4 (&acc)[2][8], bf16x8 (&bout)[
       {
         const f4& a0 = acc[c][2 * s];
         const f4& a1 = acc[c][2 * s + 1];
-        const f2v g0 = gelu2((f2v){a0[0], a0[1]}), g1 = gelu2((f2v){a0[2], a0[3]});
-        const f2v g2 = gelu2((f2v){a1[0], a1[1]}), g3 = gelu2((f2v){a1[2], a1[3]});
-        lo = (f4){g0.x, g0.y, g1.x, g1.y};
-        hi = (f4){g2.x, g2.y, g3.x, g3.y};
+        f2v gx[4] = {(f2v){a0[0], a0[1]}, (f2v){a0[2], a0[3]}, (f2v){a1[0], a1[1]}, (f2v){a1[2], a1[3]}};
+        gelu2x4(gx);
+        lo = (f4){gx[0].x, gx[0].y, gx[1].x, gx[1].y};
+        hi = (f4){gx[2].x, gx[2].y, gx[3].x, gx[3].y};
       }
       bout[c][s] = pack8(lo, hi);
       __builtin_amdgcn_sched_barrier(0);
@@ -143,7 +171,7 @@ __device__ __forceinline__ void store_z(__bf16* __restrict__ zl, const f4 (&acc)
 // STORE_Z (training): the fp32 pre-activations of the three hidden layers are kept (rounded to bf16) for the backward,
 // zbuf[head][layer][16-point block][4 KB] (blocked Z layout above).
 template <bool STORE_Z>
-__global__ __launch_bounds__(MLP_THREADS, 2) void decoder_forward_kernel(const float* __restrict__ feat,
+__global__ __launch_bounds__(FWD_THREADS, FWD_WAVES / 4) void decoder_forward_kernel(const float* __restrict__ feat,
                                                                          const float* __restrict__ pos, int N,
                                                                          const unsigned char* __restrict__ packed,
                                                                          float* attrs, __bf16* __restrict__ zbuf) {
@@ -164,7 +192,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void decoder_forward_kernel(const f
     {
       const uint4* src = reinterpret_cast<const uint4*>(packed + (size_t)head * HEAD_BYTES);
       uint4* dst = reinterpret_cast<uint4*>(wl);
-      for (int k = tid; k < HEAD_BYTES / 16; k += MLP_THREADS) dst[k] = src[k];
+      for (int k = tid; k < HEAD_BYTES / 16; k += FWD_THREADS) dst[k] = src[k];
     }
     __threadfence_block();
     __syncthreads();
@@ -173,7 +201,7 @@ __global__ __launch_bounds__(MLP_THREADS, 2) void decoder_forward_kernel(const f
     const float* b3 = b2 + HID;
     const float* b4 = b3 + HID;
 
-    for (int64_t p0 = cbeg + (int64_t)wv * SLAB; p0 < cend; p0 += (int64_t)MLP_WAVES * SLAB) {
+    for (int64_t p0 = cbeg + (int64_t)wv * SLAB; p0 < cend; p0 += (int64_t)FWD_WAVES * SLAB) {
       // ---- inputs: k-block 0 = 32 plane features, k-block 1 = info slots 4g..4g+3 (upper half of the block zero)
       bf16x8 bin[2][4];
 #pragma unroll
@@ -274,14 +302,14 @@ static int decoder_forward_impl(ggd_ctx* ctx, void* stream, const float* feat, c
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ctx->attr_mask |= GGD_ATTR_MLP_FWD;
   }
-  int grid = (N + MLP_WAVES * SLAB - 1) / (MLP_WAVES * SLAB);  // at least one slab per wave
+  int grid = (N + FWD_WAVES * SLAB - 1) / (FWD_WAVES * SLAB);  // at least one slab per wave
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
   if (zbuf)
-    hipLaunchKernelGGL(decoder_forward_kernel<true>, dim3(grid), dim3(MLP_THREADS), lds, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(decoder_forward_kernel<true>, dim3(grid), dim3(FWD_THREADS), lds, static_cast<hipStream_t>(stream),
                        feat, pos, N, static_cast<const unsigned char*>(packed_weights), attrs, static_cast<__bf16*>(zbuf));
   else
-    hipLaunchKernelGGL(decoder_forward_kernel<false>, dim3(grid), dim3(MLP_THREADS), lds, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(decoder_forward_kernel<false>, dim3(grid), dim3(FWD_THREADS), lds, static_cast<hipStream_t>(stream),
                        feat, pos, N, static_cast<const unsigned char*>(packed_weights), attrs, (__bf16*)nullptr);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
