@@ -267,11 +267,12 @@ int ggd_decoder_forward(ggd_ctx* ctx, void* stream, const float* feat, const flo
 
 /*
  * Fused decoder, TRAINING.  ggd_decoder_forward_train == ggd_decoder_forward that also keeps the hidden layers'
- * pre-activations: zbuf[5 heads][3 layers][N][128] bf16 (ggd_decoder_zbuf_bytes(N)).
+ * pre-activations: zbuf[5 heads][3 layers][ceil(N/16) blocks][16 points x 128] bf16 (ggd_decoder_zbuf_bytes(N); opaque:
+ * inside a 4 KB block the values sit in the register order of the kernels, see csrc/ggd_mlp.hip).
  * ggd_decoder_backward: given dattrs[N,16] (gradient w.r.t. the attrs rows) it back-propagates through the 5 heads
  * (last first) with the TRANSPOSED weight image packed_t (ggd_decoder_packed_t_bytes(); built by
  * fused_decoder.pack_weights_t) and writes
- *   dzbuf [5][3][N][128] bf16  gradient at every hidden pre-activation
+ *   dzbuf (same size and layout as zbuf)  gradient at every hidden pre-activation
  *   dout  [5][N][4]      fp32  gradient at every head's raw output (columns >= the head's width are zero)
  *   dfeat [N,32]         fp32  gradient w.r.t. the plane features (sum over the 5 heads)
  *   dinfo [N,16]         fp32  scratch (gradient carried between heads through the chained inputs)

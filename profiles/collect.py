@@ -23,7 +23,7 @@ def copy_stats(sub, out):
 
 copy_stats("bench", "kernel_stats.csv")
 copy_stats("train", "kernel_stats_train.csv")
-for f in ("bench.json", "bench_under_rocprof.json"):
+for f in ("bench.json", "bench_under_rocprof.json", "full_size_errors.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 for sub, out in (("pmc", "pmc_summary.txt"), ("pmc_shell", "pmc_summary_shell.txt"), ("pmc_mlp", "pmc_summary_mlp.txt")):

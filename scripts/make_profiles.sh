@@ -20,5 +20,6 @@ cd $R
 bash scripts/pmc_passes.sh $TAG/pmc scripts/fwd_only.py 1M_1024_cube 5 --backward > /dev/null
 bash scripts/pmc_passes.sh $TAG/pmc_shell scripts/fwd_only.py 1M_1024_shell 5 --backward > /dev/null
 bash scripts/pmc_passes.sh $TAG/pmc_mlp scripts/mlp_only.py 5 > /dev/null
-python bench.py --no-cpu-baseline > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench_plain.err
+python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench_plain.err
+python -m pytest tests/test_full_size_gpu.py -m gpu -q -x -s 2>&1 | grep -E "max\||passed|failed|dRGB" > gpurun_out/$TAG/full_size_errors.txt
 echo done

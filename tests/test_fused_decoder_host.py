@@ -13,7 +13,8 @@ def test_weight_images_have_the_sizes_the_library_expects():
     dec = SequentialDecoderReverse()
     assert FD.pack_weights(dec).numel() == lib.ggd_decoder_packed_bytes()
     assert FD.pack_weights_t(dec).numel() == lib.ggd_decoder_packed_t_bytes()
-    assert lib.ggd_decoder_zbuf_bytes(1000) == 5 * 3 * 1000 * 128 * 2
+    assert lib.ggd_decoder_zbuf_bytes(1000) == 5 * 3 * 1008 * 128 * 2   # 16-point blocks: N rounded up to a multiple of 16
+    assert lib.ggd_decoder_zbuf_bytes(1024) == 5 * 3 * 1024 * 128 * 2
     assert lib.ggd_decoder_wgrad_floats() == 5 * (128 * 64 + 128 + 2 * (128 * 128 + 128) + 16 * 128 + 16)
 
 
