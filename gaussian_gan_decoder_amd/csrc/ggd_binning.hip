@@ -286,6 +286,10 @@ __global__ __launch_bounds__(RS_THREADS) void sort_global_hist_kernel(const KeyT
     const int leader = __builtin_ctzll(act);
     for (int p = 0; p < passes; ++p) {
       const uint32_t d = (uint32_t)(key >> (8 * p)) & 0xffu;
+      if (p < 2) {   // the two low bytes (mantissa bits) are never shared by a wave: no point in looking
+        if (ok) atomicAdd(&s_hist[p * RS_BINS + d], 1u);
+        continue;
+      }
       const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
       if (__ballot(ok && d != d0) == 0ull) {
         if (lane == leader) atomicAdd(&s_hist[p * RS_BINS + d0], (uint32_t)__popcll(act));
