@@ -50,10 +50,12 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
   return base + inc - v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in, int64_t n,
-                                                                   uint32_t* __restrict__ block_sums) {
-  __shared__ uint32_t lds4[4];
-  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+// The three steps of the scan as workgroup-level functions: launched as their own kernels (two-call forward, sort path) or
+// run by EXTRA workgroups appended to the depth sort's first three launches (single-call forward: nothing on that path
+// reads the offsets or the total before the frame ends, so the scan needs no launches of its own -- see ggd_scan_piggy).
+__device__ __forceinline__ void scan_reduce_block(const uint32_t* __restrict__ in, int64_t n,
+                                                  uint32_t* __restrict__ block_sums, int blk, uint32_t* lds4) {
+  const int64_t base = (int64_t)blk * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   uint32_t s = 0;
   if (base + SCAN_ITEMS <= n) {
     const uint4 a = *reinterpret_cast<const uint4*>(in + base);
@@ -65,20 +67,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_
   }
   uint32_t tot;
   block_exclusive_scan_256(s, &tot, lds4);
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+  if (threadIdx.x == 0) block_sums[blk] = tot;
 }
 
-// One block turns block_sums[nb] into exclusive block prefixes (in place) and writes the grand total.
-// Rides along (one otherwise idle workgroup, an earlier launch of the same frame): the grand total also goes straight
-// into the pinned host mirror (h_total: no blit kernel for the num_rendered read-back), and `zero_words` words at
-// zero_ptr are cleared (the depth sort's histogram block: no memset launch in front of the sort).
-__global__ __launch_bounds__(SCAN_THREADS) void scan_blocksums_kernel(uint32_t* __restrict__ block_sums, int nb,
-                                                                      uint32_t* __restrict__ d_total,
-                                                                      uint32_t* h_total = nullptr,
-                                                                      uint32_t* __restrict__ zero_ptr = nullptr,
-                                                                      int zero_words = 0) {
-  __shared__ uint32_t lds4[4];
-  for (int i = threadIdx.x; i < zero_words; i += SCAN_THREADS) zero_ptr[i] = 0u;
+// One workgroup turns block_sums[nb] into exclusive block prefixes (in place) and writes the grand total -- also straight
+// into the pinned host mirror (h_total: no blit kernel for the num_rendered read-back).
+__device__ __forceinline__ void scan_blocksums_block(uint32_t* __restrict__ block_sums, int nb,
+                                                     uint32_t* __restrict__ d_total, uint32_t* h_total, uint32_t* lds4) {
   uint32_t carry = 0;
   for (int start = 0; start < nb; start += SCAN_THREADS) {
     const int i = start + threadIdx.x;
@@ -93,11 +88,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_blocksums_kernel(uint32_t* 
 }
 
 template <bool EXCLUSIVE>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t* __restrict__ in,
-                                                                  uint32_t* __restrict__ out, int64_t n,
-                                                                  const uint32_t* __restrict__ block_prefix) {
-  __shared__ uint32_t lds4[4];
-  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+__device__ __forceinline__ void scan_apply_block(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n,
+                                                 const uint32_t* __restrict__ block_prefix, int blk, uint32_t* lds4) {
+  const int64_t base = (int64_t)blk * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   uint32_t v[SCAN_ITEMS];
   const bool full = base + SCAN_ITEMS <= n;
   if (full) {
@@ -112,7 +105,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) s += v[k];
   uint32_t tot;
-  uint32_t run = block_exclusive_scan_256(s, &tot, lds4) + block_prefix[blockIdx.x];
+  uint32_t run = block_exclusive_scan_256(s, &tot, lds4) + block_prefix[blk];
   uint32_t o[SCAN_ITEMS];
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) {
@@ -128,22 +121,40 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t
   }
 }
 
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in, int64_t n,
+                                                                   uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t lds4[4];
+  scan_reduce_block(in, n, block_sums, (int)blockIdx.x, lds4);
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_blocksums_kernel(uint32_t* __restrict__ block_sums, int nb,
+                                                                      uint32_t* __restrict__ d_total,
+                                                                      uint32_t* h_total = nullptr) {
+  __shared__ uint32_t lds4[4];
+  scan_blocksums_block(block_sums, nb, d_total, h_total, lds4);
+}
+
+template <bool EXCLUSIVE>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const uint32_t* __restrict__ in,
+                                                                  uint32_t* __restrict__ out, int64_t n,
+                                                                  const uint32_t* __restrict__ block_prefix) {
+  __shared__ uint32_t lds4[4];
+  scan_apply_block<EXCLUSIVE>(in, out, n, block_prefix, (int)blockIdx.x, lds4);
+}
+
 template <bool EXCLUSIVE>
 int launch_scan(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, uint32_t* out, int64_t n, uint32_t* d_total,
-                void* tmp, size_t tmp_bytes, uint32_t* h_total = nullptr, uint32_t* zero_ptr = nullptr,
-                int zero_words = 0) {
+                void* tmp, size_t tmp_bytes, uint32_t* h_total = nullptr) {
   if (n <= 0) {
     if (d_total) GGD_HIP(hipMemsetAsync(d_total, 0, sizeof(uint32_t), s));
     if (h_total) *h_total = 0u;
-    if (zero_ptr && zero_words > 0) GGD_HIP(hipMemsetAsync(zero_ptr, 0, (size_t)zero_words * sizeof(uint32_t), s));
     return GGD_OK;
   }
   const int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
   if (tmp_bytes < (size_t)nb * sizeof(uint32_t)) return ggd_fail(ctx, GGD_E_INVALID, "scan tmp too small");
   uint32_t* block_sums = static_cast<uint32_t*>(tmp);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, block_sums);
-  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, block_sums, nb, d_total, h_total, zero_ptr,
-                     zero_words);
+  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, block_sums, nb, d_total, h_total);
   hipLaunchKernelGGL(scan_apply_kernel<EXCLUSIVE>, dim3(nb), dim3(SCAN_THREADS), 0, s, in, out, n, block_sums);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
@@ -257,10 +268,16 @@ __global__ __launch_bounds__(RS_THREADS) void sort_global_hist_kernel(const KeyT
                                                                       int passes, uint32_t* __restrict__ ghist,
                                                                       uint32_t* __restrict__ n_valid = nullptr,
                                                                       uint32_t* __restrict__ zero_ptr = nullptr,
-                                                                      size_t zero_words = 0) {
+                                                                      size_t zero_words = 0, int main_blocks = 0x7fffffff,
+                                                                      ggd_scan_piggy pg = ggd_scan_piggy{}) {
   __shared__ uint32_t s_hist[RS_MAX_PASSES * RS_BINS];
+  if ((int)blockIdx.x >= main_blocks) {   // appended workgroups: step 1 of the offsets scan (independent of the histogram)
+    scan_reduce_block(pg.in, pg.n, pg.block_sums, (int)blockIdx.x - main_blocks, s_hist);
+    return;
+  }
+  const size_t nmain = (size_t)min((int)gridDim.x, main_blocks);
   // the passes' status words are cleared here (every workgroup a slice) when the caller skipped the memset
-  for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < zero_words; i += (size_t)gridDim.x * RS_THREADS)
+  for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < zero_words; i += nmain * RS_THREADS)
     zero_ptr[i] = 0u;
   uint32_t my_valid = 0;
   for (int b = threadIdx.x; b < passes * RS_BINS; b += RS_THREADS) s_hist[b] = 0;
@@ -315,8 +332,13 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
     const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int64_t n_host, int shift, const uint32_t* __restrict__ ghist /*[256] of this pass*/,
     uint32_t* status /*[ntiles + groups][256]*/, int ntiles, int gshift, uint32_t* ticket,
-    const uint32_t* __restrict__ n_dev = nullptr) {
+    const uint32_t* __restrict__ n_dev = nullptr, int piggy_role = 0, ggd_scan_piggy pg = ggd_scan_piggy{}) {
   __shared__ uint32_t s_cnt[4][RS_BINS];   // per-wave running digit counts -> per-wave scatter bases
+  if ((int)blockIdx.x >= ntiles) {   // appended workgroups: steps 2 / 3 of the offsets scan (see ggd_scan_piggy)
+    if (piggy_role == 2) scan_blocksums_block(pg.block_sums, pg.nb, pg.d_total, pg.h_total, &s_cnt[0][0]);
+    else scan_apply_block<false>(pg.in, pg.out, pg.n, pg.block_sums, (int)blockIdx.x - ntiles, &s_cnt[0][0]);
+    return;
+  }
   __shared__ uint32_t s_scan[4];
   __shared__ uint32_t s_tile;
   __shared__ uint32_t s_flat;
@@ -468,10 +490,10 @@ int ggd_launch_inclusive_scan(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, u
 }
 
 int ggd_launch_inclusive_scan_ex(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, uint32_t* out, int64_t n,
-                                 uint32_t* d_total, void* tmp, size_t tmp_bytes, uint32_t* h_total, uint32_t* zero_ptr,
-                                 int zero_words) {
-  return launch_scan<false>(ctx, s, in, out, n, d_total, tmp, tmp_bytes, h_total, zero_ptr, zero_words);
+                                 uint32_t* d_total, void* tmp, size_t tmp_bytes, uint32_t* h_total) {
+  return launch_scan<false>(ctx, s, in, out, n, d_total, tmp, tmp_bytes, h_total);
 }
+int ggd_scan_blocks(int64_t n) { return n > 0 ? (int)((n + SCAN_TILE - 1) / SCAN_TILE) : 0; }
 
 int ggd_launch_duplicate(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect, const uint32_t* depth_keys,
                          const uint32_t* tiles_touched, const uint32_t* offsets, uint64_t* keys, uint32_t* vals) {
@@ -536,7 +558,7 @@ size_t ggd_sort_ctrl_words() { return sort_ctrl_bytes() / sizeof(uint32_t); }
 
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
-                           uint32_t* clean_ctl) {
+                           uint32_t* clean_ctl, const ggd_scan_piggy* piggy) {
   if (n <= 0) return GGD_OK;
   const int passes = sort_passes(nbits);
   if (passes > RS_MAX_PASSES || (passes & 1)) return ggd_fail(ctx, GGD_E_INVALID, "sort32: need an even pass count");
@@ -555,9 +577,12 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
   // keys equal to 0xFFFFFFFF (culled Gaussians) are dropped by pass 0; n_valid (device) = number of kept keys, the
   // element count of every later pass and of the binning that consumes the order (word RS_MAX_PASSES of the tickets)
   uint32_t* n_valid = tickets + RS_MAX_PASSES;
-  hipLaunchKernelGGL((sort_global_hist_kernel<uint32_t, RS32_ITEMS, true>), dim3(ntiles), dim3(RS_THREADS), 0, s,
+  // the offsets scan rides on the first three launches as appended workgroups (reduce | block sums | apply)
+  const ggd_scan_piggy pg = piggy ? *piggy : ggd_scan_piggy{};
+  const int pnb = piggy ? pg.nb : 0;
+  hipLaunchKernelGGL((sort_global_hist_kernel<uint32_t, RS32_ITEMS, true>), dim3(ntiles + pnb), dim3(RS_THREADS), 0, s,
                      keys_src, n, passes, ghist, n_valid, clean_ctl ? status : nullptr,
-                     clean_ctl ? status_bytes / sizeof(uint32_t) : (size_t)0);
+                     clean_ctl ? status_bytes / sizeof(uint32_t) : (size_t)0, ntiles, pg);
   // pass 0: keys_src (read-only, caller's buffer) -> B with identity values; then B -> A -> B -> A ...
   const uint32_t* kin = keys_src;
   const uint32_t* vin = nullptr;
@@ -565,12 +590,13 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
     uint32_t* kout = (p & 1) ? keys_a : keys_b;
     uint32_t* vout = (p & 1) ? vals_a : vals_b;
     if (p == 0)
-      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, true, RS32_ITEMS, true>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin,
-                         vin, kout, vout, n, 0, ghist, status, ntiles, gshift, tickets, n_valid);
+      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, true, RS32_ITEMS, true>), dim3(ntiles + (pnb ? 1 : 0)),
+                         dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 0, ghist, status, ntiles, gshift, tickets, n_valid,
+                         2, pg);
     else
-      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true>), dim3(ntiles), dim3(RS_THREADS), 0, s, kin,
-                         vin, kout, vout, n, 8 * p, ghist + p * RS_BINS, status + (size_t)p * pass_words, ntiles, gshift,
-                         tickets + p, n_valid);
+      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true>), dim3(ntiles + (p == 1 ? pnb : 0)),
+                         dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 8 * p, ghist + p * RS_BINS,
+                         status + (size_t)p * pass_words, ntiles, gshift, tickets + p, n_valid, 3, pg);
     kin = kout; vin = vout;
   }
   GGD_HIP(hipGetLastError());

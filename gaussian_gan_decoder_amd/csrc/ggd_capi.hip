@@ -143,6 +143,7 @@ extern "C" void ggd_destroy(ggd_ctx* ctx) {
   if (ctx->d_words) (void)hipFree(ctx->d_words);
   if (ctx->h_words) (void)hipHostFree(ctx->h_words);
   if (ctx->sortctl) (void)hipFree(ctx->sortctl);
+  if (ctx->scan_sums) (void)hipFree(ctx->scan_sums);
   if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);
   if (ctx->dbg_vals) (void)hipFree(ctx->dbg_vals);
   for (int i = 0; i < 2 * ST_COUNT; ++i)
@@ -233,7 +234,7 @@ static int check_inputs(ggd_ctx* ctx, const ggd_params* prm, const float* means3
 static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D,
                             const float* shs, const float* colors_precomp, const float* opacities,
                             const float* scales, const float* rotations, const float* cov3D_precomp,
-                            void* geom_buf, int32_t* radii, int64_t* num_rendered) {
+                            void* geom_buf, int32_t* radii, int64_t* num_rendered, bool defer_scan = false) {
   int rc = check_params(ctx, prm);
   if (rc != GGD_OK) return rc;
   rc = check_inputs(ctx, prm, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp);
@@ -263,15 +264,30 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
     StageTimer t(ctx, ST_PREPROCESS, s);
     rc = ggd_launch_preprocess(ctx, s, *prm, means3D, shs, colors_precomp, opacities, scales, rotations,
                                cov3D_precomp, splat, tiles, shs ? clamped : nullptr, radii, depth_keys, rect,
-                               ctx->d_words + 1);
+                               ctx->d_words + 1, ctx->sortctl, ctx->sortctl ? (int)ggd_sort_ctrl_words() : 0);
     if (rc != GGD_OK) return rc;
+    ctx->sortctl_clean = ctx->sortctl != nullptr;
+  }
+  ctx->scan_deferred = false;
+  if (defer_scan && ctx->h_words_dev) {
+    // single-call forward on a tile-binning path: the scan (offsets + num_rendered) rides on the depth sort's launches
+    const int nb = ggd_scan_blocks(prm->P);
+    if (ctx->scan_sums_cap < nb) {
+      if (ctx->scan_sums) (void)hipFree(ctx->scan_sums);
+      ctx->scan_sums = nullptr; ctx->scan_sums_cap = 0;
+      GGD_HIP(hipMalloc((void**)&ctx->scan_sums, (size_t)(nb + nb / 2 + 64) * sizeof(uint32_t)));
+      ctx->scan_sums_cap = nb + nb / 2 + 64;
+    }
+    ctx->scan_deferred = true;
+    if (prm->prefiltered)
+      GGD_HIP(hipMemcpyAsync(ctx->h_words + 1, ctx->d_words + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    return GGD_OK;
   }
   {
     StageTimer t(ctx, ST_SCAN, s);
     rc = ggd_launch_inclusive_scan_ex(ctx, s, tiles, offsets, prm->P, ctx->d_words, ctx->scratch, ctx->scratch_bytes,
-                                      ctx->h_words_dev, ctx->sortctl, ctx->sortctl ? (int)ggd_sort_ctrl_words() : 0);
+                                      ctx->h_words_dev);
     if (rc != GGD_OK) return rc;
-    ctx->sortctl_clean = ctx->sortctl != nullptr;
   }
   {
     StageTimer t(ctx, ST_READBACK, s);
@@ -366,7 +382,16 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
       // falls back to the memset)
       clean_ctl = ctx->sortctl_clean ? ctx->sortctl : nullptr;
       ctx->sortctl_clean = false;
-      rc = ggd_launch_sort32_iota(ctx, s, depth_keys, ka, va, kb, vb, prm->P, 32, tmp, sort_tmp, clean_ctl);
+      ggd_scan_piggy pg;
+      if (ctx->scan_deferred) {   // this call's geometry half left the scan to us
+        uint32_t* tiles_w = reinterpret_cast<uint32_t*>(const_cast<char*>(gb) + gv.tiles_touched);
+        pg.in = tiles_w; pg.out = reinterpret_cast<uint32_t*>(const_cast<char*>(gb) + gv.point_offsets);
+        pg.n = prm->P; pg.nb = ggd_scan_blocks(prm->P); pg.block_sums = ctx->scan_sums;
+        pg.d_total = ctx->d_words; pg.h_total = ctx->h_words_dev;
+      }
+      rc = ggd_launch_sort32_iota(ctx, s, depth_keys, ka, va, kb, vb, prm->P, 32, tmp, sort_tmp, clean_ctl,
+                                  ctx->scan_deferred ? &pg : nullptr);
+      ctx->scan_deferred = false;
       if (rc != GGD_OK) return rc;
     }
     {
@@ -442,8 +467,9 @@ extern "C" int ggd_forward(ggd_ctx* ctx, void* stream, const ggd_params* prm, co
                            void* binning_buf, int64_t capacity, void* img_buf, float* out_color,
                            int64_t* num_rendered) {
   if (capacity < 0) return ggd_fail(ctx, GGD_E_INVALID, "capacity < 0");
+  const bool spec = prm && prm->P > 0 && ggd_forward_can_speculate(ctx, prm, capacity) != 0;
   int rc = geometry_enqueue(ctx, stream, prm, means3D, shs, colors_precomp, opacities, scales, rotations,
-                            cov3D_precomp, geom_buf, radii, num_rendered);
+                            cov3D_precomp, geom_buf, radii, num_rendered, spec && capacity > 0);
   if (rc != GGD_OK) return rc;
   if (prm->P == 0) return render_enqueue(ctx, stream, prm, geom_buf, capacity, 0, binning_buf, img_buf, out_color, false);
   if (ggd_forward_can_speculate(ctx, prm, capacity)) {

@@ -32,7 +32,10 @@ struct ggd_ctx {
   uint32_t* h_words = nullptr;  // pinned host mirror
   uint32_t* h_words_dev = nullptr;  // the same memory as the device sees it (the scan writes num_rendered there itself)
   uint32_t* sortctl = nullptr;      // depth sort's control block (histograms, tickets, kept-key count) in its own allocation
-  bool sortctl_clean = false;       // cleared by this frame's scan and not yet consumed by a sort
+  bool sortctl_clean = false;       // cleared by this frame's preprocess and not yet consumed by a sort
+  uint32_t* scan_sums = nullptr;    // block sums of a scan that rides on the depth sort (own allocation, grow-only)
+  int scan_sums_cap = 0;
+  bool scan_deferred = false;       // geometry_enqueue left the scan to the sort launches of the same call
   void* dbg_keys = nullptr;     // debug copy of the unsorted list
   void* dbg_vals = nullptr;
   size_t dbg_cap = 0;
@@ -42,6 +45,20 @@ struct ggd_ctx {
   hipEvent_t ev[2 * ST_COUNT] = {};
   bool ev_used[ST_COUNT] = {};
   std::string err;
+};
+
+// The offsets scan of stage a5 as a passenger of the depth sort (single-call forward): its three steps are run by extra
+// workgroups appended to the sort's histogram / pass-0 / pass-1 launches -- each step only depends on the previous
+// launch, and nothing on the tile-binning paths reads the offsets or the total before the frame ends -- so the scan
+// costs no launches of its own (three launches of ~4.8 us each otherwise).
+struct ggd_scan_piggy {
+  const uint32_t* in = nullptr;   // tiles_touched[n]
+  uint32_t* out = nullptr;        // point_offsets[n] (inclusive)
+  int64_t n = 0;
+  int nb = 0;                     // ggd_scan_blocks(n)
+  uint32_t* block_sums = nullptr; // [nb] scratch
+  uint32_t* d_total = nullptr;    // device word for the grand total (num_rendered)
+  uint32_t* h_total = nullptr;    // device view of the pinned host word (may be NULL)
 };
 
 int ggd_fail(ggd_ctx* ctx, int code, const std::string& msg);
@@ -71,17 +88,18 @@ int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, co
                           const float* shs, const float* colors_precomp, const float* opacities,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           ggd_splat* splat, uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii,
-                          uint32_t* depth_keys, uint2* rect, uint32_t* trap_flag);
+                          uint32_t* depth_keys, uint2* rect, uint32_t* trap_flag, uint32_t* zero_ptr = nullptr,
+                          int zero_words = 0);   // zero_words words at zero_ptr are cleared by the first workgroups
 int ggd_launch_mark_visible(ggd_ctx* ctx, hipStream_t s, int P, const float* means3D, const float* view,
                             uint8_t* present);
 // inclusive scan of a uint32 array; total written to *d_total (device)
 int ggd_launch_inclusive_scan(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, uint32_t* out, int64_t n,
                               uint32_t* d_total, void* tmp, size_t tmp_bytes);
 size_t ggd_scan_tmp_bytes(int64_t n);
-// same, plus: total also written to h_total (device view of a pinned host word) and zero_words words cleared at zero_ptr
+// same, plus: total also written to h_total (device view of a pinned host word)
 int ggd_launch_inclusive_scan_ex(ggd_ctx* ctx, hipStream_t s, const uint32_t* in, uint32_t* out, int64_t n,
-                                 uint32_t* d_total, void* tmp, size_t tmp_bytes, uint32_t* h_total, uint32_t* zero_ptr,
-                                 int zero_words);
+                                 uint32_t* d_total, void* tmp, size_t tmp_bytes, uint32_t* h_total);
+int ggd_scan_blocks(int64_t n);   // workgroups (= block sums) of the scan over n elements
 size_t ggd_sort_ctrl_words();   // words of the depth sort's control block (ggd_launch_sort32_iota's clean_ctl)
 int ggd_launch_duplicate(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect,
                          const uint32_t* depth_keys, const uint32_t* tiles_touched, const uint32_t* offsets,
@@ -98,7 +116,7 @@ int ggd_launch_sort(ggd_ctx* ctx, hipStream_t s, uint64_t* keys_a, uint32_t* val
 // values start as the identity permutation.  nbits must be a multiple of 16 (even number of passes).
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
-                           uint32_t* clean_ctl = nullptr);
+                           uint32_t* clean_ctl = nullptr, const ggd_scan_piggy* piggy = nullptr);
 // Tile binning (GGD_OPT_BINNING = 1): sorted Gaussian order -> per-tile lists + ranges.
 bool ggd_rowbin_supported(int W, int H);
 size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity);

@@ -19,7 +19,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, ggd_splat* __restrict__ splat, uint32_t* __restrict__ tiles_touched,
     uint8_t* __restrict__ clamped, int32_t* __restrict__ radii, uint32_t* __restrict__ depth_keys,
-    uint2* __restrict__ rect, uint32_t* __restrict__ trap_flag) {
+    uint2* __restrict__ rect, uint32_t* __restrict__ trap_flag, uint32_t* __restrict__ zero_ptr, int zero_words) {
+  // first kernel of a frame: its first workgroups also clear the depth sort's control block (no memset launch there)
+  {
+    const int zb = min(8, (int)gridDim.x);
+    if ((int)blockIdx.x < zb)
+      for (int z = blockIdx.x * 256 + threadIdx.x; z < zero_words; z += zb * 256) zero_ptr[z] = 0u;
+  }
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P) return;
   const Mat16 V = load_mat(view);
@@ -152,13 +158,14 @@ int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, co
                           const float* shs, const float* colors_precomp, const float* opacities,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           ggd_splat* splat, uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii,
-                          uint32_t* depth_keys, uint2* rect, uint32_t* trap_flag) {
+                          uint32_t* depth_keys, uint2* rect, uint32_t* trap_flag, uint32_t* zero_ptr, int zero_words) {
   if (prm.P == 0) return GGD_OK;
   const int grid = (prm.P + 255) / 256;
   hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, s, prm.P, prm.M, prm.sh_degree, prm.width,
                      prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.raw_attributes, prm.viewmatrix,
                      prm.projmatrix, prm.campos, means3D, shs, colors_precomp, opacities, scales, rotations,
-                     cov3D_precomp, splat, tiles_touched, clamped, radii, depth_keys, rect, trap_flag);
+                     cov3D_precomp, splat, tiles_touched, clamped, radii, depth_keys, rect, trap_flag, zero_ptr,
+                     zero_ptr ? zero_words : 0);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }
