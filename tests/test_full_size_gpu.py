@@ -143,3 +143,30 @@ def test_full_size_matches_oracle(native_lib, kind):
                     f"{r['max_rel_err_on_large']:.2e} max|value|={r['max_abs_value']:.3e} "
                     f"worst |err|/tol={r['worst_ratio']:.3f}" for r in report))
     assert worst <= 1.0, f"gradient outside its fp32 error budget (worst ratio {worst:.2f})"
+
+
+def test_many_gaussians_beyond_the_resident_tile_count(native_lib):
+    """4.6 M Gaussians: the depth sort has more tiles (1123) than the 1024 it treats as certainly resident, i.e. tile indices
+    come from the ticket while the offsets scan rides on the same launches as appended workgroups; also a speculative
+    (single-call) forward.  Checked through invariants (no oracle run at this size) and path independence."""
+    d = scene_inputs(P=4_600_000, size=512, kind="cube", seed=3, use_colors=True, lsm=-6.5)
+    n_first = run_native(d, debug=False)                 # two-call form (records the capacity hint)
+    n = run_native(d, debug=False)                       # single-call form: scan as a passenger of the sort
+    P, R = d["P"], n["num_rendered"]
+    assert R == n_first["num_rendered"] and R > 1_000_000
+    tiles = n["tiles_touched"].astype(np.int64)
+    assert R == int(tiles.sum())
+    np.testing.assert_array_equal(n["point_offsets"].astype(np.int64), np.cumsum(tiles))
+    np.testing.assert_array_equal(n["point_list"], n_first["point_list"])
+    np.testing.assert_array_equal(n["ranges"], n_first["ranges"])
+    assert torch.equal(n["color"], n_first["color"])
+    lst = n["point_list"].astype(np.int64)
+    np.testing.assert_array_equal(np.bincount(lst, minlength=P), tiles)
+    rg = n["ranges"].astype(np.int64)
+    tile_of = np.repeat(np.arange(rg.shape[0]), (rg[:, 1] - rg[:, 0]))
+    key = n["depths"].view(np.uint32)[lst].astype(np.int64) * (1 << 32) + lst
+    same = tile_of[1:] == tile_of[:-1]
+    assert (key[1:][same] > key[:-1][same]).all()
+    n_sort = run_native(d, debug=False, binning=0)       # the radix-sort path builds the same lists
+    np.testing.assert_array_equal(n_sort["point_list"], n["point_list"])
+    np.testing.assert_array_equal(n_sort["ranges"], n["ranges"])
