@@ -175,6 +175,18 @@ def context_for(device) -> Context:
     return ctx
 
 
+def context_and_stream(device):
+    """(context of the current stream of `device`, that stream's raw handle) with one current_stream lookup."""
+    import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    handle = int(torch.cuda.current_stream(idx).cuda_stream)
+    key = (idx, handle)
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = _contexts[key] = Context(idx)
+    return ctx, handle
+
+
 def geom_view(P: int) -> GeomView:
     v = GeomView(); load().ggd_geom_layout(P, C.byref(v)); return v
 

@@ -558,7 +558,7 @@ size_t ggd_sort_ctrl_words() { return sort_ctrl_bytes() / sizeof(uint32_t); }
 
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
-                           uint32_t* clean_ctl, const ggd_scan_piggy* piggy) {
+                           uint32_t* clean_ctl, const ggd_scan_piggy* piggy, hipEvent_t total_ready) {
   if (n <= 0) return GGD_OK;
   const int passes = sort_passes(nbits);
   if (passes > RS_MAX_PASSES || (passes & 1)) return ggd_fail(ctx, GGD_E_INVALID, "sort32: need an even pass count");
@@ -593,7 +593,8 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
       hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, true, RS32_ITEMS, true>), dim3(ntiles + (pnb ? 1 : 0)),
                          dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 0, ghist, status, ntiles, gshift, tickets, n_valid,
                          2, pg);
-    else
+    if (p == 0 && pnb && total_ready) GGD_HIP(hipEventRecord(total_ready, s));   // num_rendered is on its way to the host
+    if (p != 0)
       hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true>), dim3(ntiles + (p == 1 ? pnb : 0)),
                          dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 8 * p, ghist + p * RS_BINS,
                          status + (size_t)p * pass_words, ntiles, gshift, tickets + p, n_valid, 3, pg);

@@ -123,6 +123,10 @@ extern "C" ggd_ctx* ggd_create(int device) {
     ctx->h_words_dev = nullptr;
     (void)hipGetLastError();
   }
+  if (ok && hipEventCreateWithFlags(&ctx->ev_r, hipEventDisableTiming) != hipSuccess) {
+    ctx->ev_r = nullptr;
+    (void)hipGetLastError();
+  }
   if (ok && (hipMalloc((void**)&ctx->sortctl, ggd_sort_ctrl_words() * sizeof(uint32_t)) != hipSuccess ||
              hipMemset(ctx->sortctl, 0, ggd_sort_ctrl_words() * sizeof(uint32_t)) != hipSuccess)) {
     ctx->sortctl = nullptr;
@@ -144,6 +148,7 @@ extern "C" void ggd_destroy(ggd_ctx* ctx) {
   if (ctx->h_words) (void)hipHostFree(ctx->h_words);
   if (ctx->sortctl) (void)hipFree(ctx->sortctl);
   if (ctx->scan_sums) (void)hipFree(ctx->scan_sums);
+  if (ctx->ev_r) (void)hipEventDestroy(ctx->ev_r);
   if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);
   if (ctx->dbg_vals) (void)hipFree(ctx->dbg_vals);
   for (int i = 0; i < 2 * ST_COUNT; ++i)
@@ -302,7 +307,15 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
 
 // Wait for the stream and publish R (the one host sync of a forward).
 static int geometry_finish(ggd_ctx* ctx, void* stream, const ggd_params* prm, int64_t* num_rendered) {
-  GGD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  // The host needs num_rendered, not the finished frame: in the single-call forward it waits for the event behind the
+  // launch that delivered R (early in the depth sort) and returns while binning and blend are still running -- as
+  // upstream returns with its render kernels in flight.  Outputs are ordered on the caller's stream as usual.
+  if (ctx->ev_r_pending) {
+    ctx->ev_r_pending = false;
+    GGD_HIP(hipEventSynchronize(ctx->ev_r));
+  } else {
+    GGD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  }
   if (prm->prefiltered && ctx->h_words[1] != 0)
     return ggd_fail(ctx, GGD_E_PREFILTER, "Point is filtered although prefiltered is set. This shouldn't happen!");
   *num_rendered = (int64_t)ctx->h_words[0];
@@ -389,8 +402,10 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
         pg.n = prm->P; pg.nb = ggd_scan_blocks(prm->P); pg.block_sums = ctx->scan_sums;
         pg.d_total = ctx->d_words; pg.h_total = ctx->h_words_dev;
       }
+      const bool riding = ctx->scan_deferred;
       rc = ggd_launch_sort32_iota(ctx, s, depth_keys, ka, va, kb, vb, prm->P, 32, tmp, sort_tmp, clean_ctl,
-                                  ctx->scan_deferred ? &pg : nullptr);
+                                  riding ? &pg : nullptr, riding ? ctx->ev_r : nullptr);
+      ctx->ev_r_pending = riding && ctx->ev_r != nullptr && rc == GGD_OK;
       ctx->scan_deferred = false;
       if (rc != GGD_OK) return rc;
     }

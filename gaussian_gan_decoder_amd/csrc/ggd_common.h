@@ -36,6 +36,8 @@ struct ggd_ctx {
   uint32_t* scan_sums = nullptr;    // block sums of a scan that rides on the depth sort (own allocation, grow-only)
   int scan_sums_cap = 0;
   bool scan_deferred = false;       // geometry_enqueue left the scan to the sort launches of the same call
+  hipEvent_t ev_r = nullptr;        // recorded right after the launch that delivers num_rendered (single-call forward)
+  bool ev_r_pending = false;        // ... and not yet waited for: the host waits for THAT, not for the end of the frame
   void* dbg_keys = nullptr;     // debug copy of the unsorted list
   void* dbg_vals = nullptr;
   size_t dbg_cap = 0;
@@ -116,7 +118,8 @@ int ggd_launch_sort(ggd_ctx* ctx, hipStream_t s, uint64_t* keys_a, uint32_t* val
 // values start as the identity permutation.  nbits must be a multiple of 16 (even number of passes).
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
-                           uint32_t* clean_ctl = nullptr, const ggd_scan_piggy* piggy = nullptr);
+                           uint32_t* clean_ctl = nullptr, const ggd_scan_piggy* piggy = nullptr,
+                           hipEvent_t total_ready = nullptr);   // recorded after the launch that writes piggy's total
 // Tile binning (GGD_OPT_BINNING = 1): sorted Gaussian order -> per-tile lists + ranges.
 bool ggd_rowbin_supported(int W, int H);
 size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity);

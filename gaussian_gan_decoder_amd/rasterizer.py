@@ -63,6 +63,36 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if (t is None or t.numel() == 0) else C.c_void_p(t.data_ptr())
 
 
+_size_cache: dict = {}
+
+
+def _sizes(kind: str, a: int, b: int) -> int:
+    """ggd_geom_bytes(P) / ggd_img_bytes(W, H) / ggd_binning_bytes(R), memoised (pure functions of their arguments)."""
+    k = (kind, a, b)
+    v = _size_cache.get(k)
+    if v is None:
+        lib = _capi.load()
+        v = int(lib.ggd_geom_bytes(a) if kind == "g" else (lib.ggd_img_bytes(a, b) if kind == "i" else lib.ggd_binning_bytes(a)))
+        if len(_size_cache) > 4096:
+            _size_cache.clear()
+        _size_cache[k] = v
+    return v
+
+
+class _NoGuard:
+    def __enter__(self): return None
+    def __exit__(self, *a): return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _device_guard(dev):
+    """torch.cuda.device(dev) only when another device is current (the context manager costs ~5 us per call)."""
+    idx = dev.index
+    return _NO_GUARD if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(dev)
+
+
 def _stream(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -116,25 +146,27 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
                                        viewmatrix, projmatrix, degree, campos, prefiltered, debug, raw_attributes)
     keep: list = []
     prm = _params(rs, P, M, dev, keep)
-    ctx = _capi.context_for(dev)
+    # (the GPU idles while this wrapper runs between two frames of a render loop: sizes are cached, the stream is looked
+    # up once, and the device guard is only entered when another device is current)
+    ctx, stream_handle = _capi.context_and_stream(dev)
     lib = ctx.lib
     H, W = int(image_height), int(image_width)
     u8 = dict(dtype=torch.uint8, device=dev)
     color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
-    geom = torch.empty((lib.ggd_geom_bytes(P),), **u8)
-    img = torch.empty((lib.ggd_img_bytes(W, H),), **u8)
+    geom = torch.empty((_sizes("g", P, 0),), **u8)
+    img = torch.empty((_sizes("i", W, H),), **u8)
     R = C.c_int64(0)
-    stream = _stream(dev)
+    stream = C.c_void_p(stream_handle)
     key = (P, W, H)
     hint = ctx.capacity_hint.get(key)
-    with torch.cuda.device(dev):
+    with _device_guard(dev):
         binning = None
         if hint is not None and P > 0 and not debug:   # debug: exact two-call form, buffers laid out for num_rendered
             # single-call forward: binning buffer sized from the previous frame of this shape (+25 %); the GPU does
             # not wait for the num_rendered round trip.  Falls through to the exact two-phase path on overflow.
             cap = int(hint * 1.25) + 65536
-            binning = torch.empty((lib.ggd_binning_bytes(cap),), **u8)
+            binning = torch.empty((_sizes("b", cap, 0),), **u8)
             rc = lib.ggd_forward(ctx.handle, stream, C.byref(prm), _ptr(means3D), _ptr(sh_c), _ptr(col_c),
                                  _ptr(opacities), _ptr(sc_c), _ptr(rot_c), _ptr(cov_c), _ptr(geom), _ptr(radii),
                                  _ptr(binning), cap, _ptr(img), _ptr(color), C.byref(R))
