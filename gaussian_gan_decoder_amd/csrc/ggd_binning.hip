@@ -332,7 +332,8 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
     const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int64_t n_host, int shift, const uint32_t* __restrict__ ghist /*[256] of this pass*/,
     uint32_t* status /*[ntiles + groups][256]*/, int ntiles, int gshift, uint32_t* ticket,
-    const uint32_t* __restrict__ n_dev = nullptr, int piggy_role = 0, ggd_scan_piggy pg = ggd_scan_piggy{}) {
+    const uint32_t* __restrict__ n_dev = nullptr, int piggy_role = 0, ggd_scan_piggy pg = ggd_scan_piggy{},
+    uint32_t* __restrict__ flat_flag = nullptr) {
   __shared__ uint32_t s_cnt[4][RS_BINS];   // per-wave running digit counts -> per-wave scatter bases
   if ((int)blockIdx.x >= ntiles) {   // appended workgroups: steps 2 / 3 of the offsets scan (see ggd_scan_piggy)
     if (piggy_role == 2) scan_blocksums_block(pg.block_sums, pg.nb, pg.d_total, pg.h_total, &s_cnt[0][0]);
@@ -376,6 +377,10 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
     if ((int64_t)my_bin == n) s_flat = 1u;
     __syncthreads();
     if (s_flat != 0u) {
+      if (flat_flag) {   // last pass: the consumer reads the input buffer instead (no copy at all)
+        if (tile == 0u && threadIdx.x == 0) *flat_flag = 1u;
+        return;
+      }
 #pragma unroll
       for (int r = 0; r < ITEMS; ++r) {
         const int64_t idx = wbase + r * 64 + lane;
@@ -554,11 +559,15 @@ const uint32_t* ggd_sort32_nvalid_ptr(const void* tmp) {
   return static_cast<const uint32_t*>(tmp) + RS_HWORDS + RS_MAX_PASSES;
 }
 
+const uint32_t* ggd_sort32_flat_ptr(const void* ctl) {
+  return static_cast<const uint32_t*>(ctl) + RS_HWORDS + RS_MAX_PASSES + 1;
+}
+
 size_t ggd_sort_ctrl_words() { return sort_ctrl_bytes() / sizeof(uint32_t); }
 
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
-                           uint32_t* clean_ctl, const ggd_scan_piggy* piggy, hipEvent_t total_ready) {
+                           uint32_t* clean_ctl, const ggd_scan_piggy* piggy, hipEvent_t total_ready, bool flag_flat_last) {
   if (n <= 0) return GGD_OK;
   const int passes = sort_passes(nbits);
   if (passes > RS_MAX_PASSES || (passes & 1)) return ggd_fail(ctx, GGD_E_INVALID, "sort32: need an even pass count");
@@ -597,7 +606,8 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
     if (p != 0)
       hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true>), dim3(ntiles + (p == 1 ? pnb : 0)),
                          dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 8 * p, ghist + p * RS_BINS,
-                         status + (size_t)p * pass_words, ntiles, gshift, tickets + p, n_valid, 3, pg);
+                         status + (size_t)p * pass_words, ntiles, gshift, tickets + p, n_valid, 3, pg,
+                         (flag_flat_last && p == passes - 1) ? tickets + RS_MAX_PASSES + 1 : nullptr);
     kin = kout; vin = vout;
   }
   GGD_HIP(hipGetLastError());

@@ -404,7 +404,7 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
       }
       const bool riding = ctx->scan_deferred;
       rc = ggd_launch_sort32_iota(ctx, s, depth_keys, ka, va, kb, vb, prm->P, 32, tmp, sort_tmp, clean_ctl,
-                                  riding ? &pg : nullptr, riding ? ctx->ev_r : nullptr);
+                                  riding ? &pg : nullptr, riding ? ctx->ev_r : nullptr, rowbin);
       ctx->ev_r_pending = riding && ctx->ev_r != nullptr && rc == GGD_OK;
       ctx->scan_deferred = false;
       if (rc != GGD_OK) return rc;
@@ -413,7 +413,9 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
       StageTimer t(ctx, ST_DUPLICATE, s);
       // the depth sort dropped the culled Gaussians (key 0xFFFFFFFF) and left the number of kept ones on the device
       const uint32_t* n_vis = ggd_sort32_nvalid_ptr(clean_ctl ? static_cast<const void*>(clean_ctl) : tmp);
-      rc = rowbin ? ggd_launch_rowbin(ctx, s, *prm, rect, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp)
+      const void* ctl = clean_ctl ? static_cast<const void*>(clean_ctl) : tmp;
+      rc = rowbin ? ggd_launch_rowbin(ctx, s, *prm, rect, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp, vb,
+                                      ggd_sort32_flat_ptr(ctl))
                   : ggd_launch_tilebin(ctx, s, *prm, rect, tiles, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp);
       if (rc != GGD_OK) return rc;
     }

@@ -51,8 +51,11 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
 __global__ __launch_bounds__(RB_THREADS) void rb_count1_kernel(int W, int H, const uint2* __restrict__ rect,
                                                                const uint32_t* __restrict__ order,
                                                                const uint32_t* __restrict__ n_vis_ptr, int P,
-                                                               uint2* __restrict__ packed, uint32_t* __restrict__ counts1) {
+                                                               uint2* __restrict__ packed, uint32_t* __restrict__ counts1,
+                                                               const uint32_t* __restrict__ order_alt,
+                                                               const uint32_t* __restrict__ use_alt) {
   __shared__ int diff[65];
+  if (use_alt && *use_alt != 0u) order = order_alt;   // the depth sort's last pass was the identity and copied nothing
   const uint32_t n_vis = min((uint32_t)P, *n_vis_ptr);
   const uint32_t base = (uint32_t)blockIdx.x * RB_CHUNK;
   if (base >= n_vis) return;
@@ -360,7 +363,7 @@ size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity) {
 // capacity: upper bound on num_rendered (the level-1 entry count is <= num_rendered); order = depth-sorted ids.
 int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect, const uint32_t* order,
                       const uint32_t* n_vis_ptr, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
-                      size_t tmp_bytes) {
+                      size_t tmp_bytes, const uint32_t* order_alt, const uint32_t* use_alt) {
   if (!ggd_rowbin_supported(prm.width, prm.height)) return ggd_fail(ctx, GGD_E_INVALID, "tile grid too large for row binning");
   if (tmp_bytes < ggd_rowbin_tmp_bytes(prm.P, capacity)) return ggd_fail(ctx, GGD_E_INVALID, "rowbin tmp too small");
   const int gx = (prm.width + 15) / 16, gy = (prm.height + 15) / 16;
@@ -373,7 +376,7 @@ int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const 
   const int nb1 = rb_blocks1(prm.P);
   const uint32_t nb2 = rb_blocks2(capacity);
   hipLaunchKernelGGL(rb_count1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, prm.width, prm.height, rect, order,
-                     n_vis_ptr, prm.P, packed, counts1);
+                     n_vis_ptr, prm.P, packed, counts1, order_alt, use_alt);
   hipLaunchKernelGGL(rb_scan1_kernel, dim3(1), dim3(1024), 0, s, counts1, n_vis_ptr, prm.P, tab, capacity);
   hipLaunchKernelGGL(rb_scatter1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, packed, n_vis_ptr, prm.P, counts1, tab,
                      ent, capacity);
