@@ -73,7 +73,8 @@ __device__ __forceinline__ void scan_reduce_block(const uint32_t* __restrict__ i
 // One workgroup turns block_sums[nb] into exclusive block prefixes (in place) and writes the grand total -- also straight
 // into the pinned host mirror (h_total: no blit kernel for the num_rendered read-back).
 __device__ __forceinline__ void scan_blocksums_block(uint32_t* __restrict__ block_sums, int nb,
-                                                     uint32_t* __restrict__ d_total, uint32_t* h_total, uint32_t* lds4) {
+                                                     uint32_t* __restrict__ d_total, uint32_t* h_total, uint32_t* lds4,
+                                                     unsigned long long* h_tagged = nullptr, uint32_t tag = 0) {
   uint32_t carry = 0;
   for (int start = 0; start < nb; start += SCAN_THREADS) {
     const int i = start + threadIdx.x;
@@ -85,6 +86,9 @@ __device__ __forceinline__ void scan_blocksums_block(uint32_t* __restrict__ bloc
   }
   if (threadIdx.x == 0 && d_total) *d_total = carry;
   if (threadIdx.x == 0 && h_total) { *h_total = carry; __threadfence_system(); }
+  if (threadIdx.x == 0 && h_tagged) {   // one 64-bit store: the host sees tag and total together
+    __hip_atomic_store(h_tagged, ((unsigned long long)tag << 32) | carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 template <bool EXCLUSIVE>
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
     uint32_t* __restrict__ flat_flag = nullptr) {
   __shared__ uint32_t s_cnt[4][RS_BINS];   // per-wave running digit counts -> per-wave scatter bases
   if ((int)blockIdx.x >= ntiles) {   // appended workgroups: steps 2 / 3 of the offsets scan (see ggd_scan_piggy)
-    if (piggy_role == 2) scan_blocksums_block(pg.block_sums, pg.nb, pg.d_total, pg.h_total, &s_cnt[0][0]);
+    if (piggy_role == 2) scan_blocksums_block(pg.block_sums, pg.nb, pg.d_total, pg.h_total, &s_cnt[0][0], pg.h_tagged, pg.tag);
     else scan_apply_block<false>(pg.in, pg.out, pg.n, pg.block_sums, (int)blockIdx.x - ntiles, &s_cnt[0][0]);
     return;
   }
@@ -567,7 +571,7 @@ size_t ggd_sort_ctrl_words() { return sort_ctrl_bytes() / sizeof(uint32_t); }
 
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
-                           uint32_t* clean_ctl, const ggd_scan_piggy* piggy, hipEvent_t total_ready, bool flag_flat_last) {
+                           uint32_t* clean_ctl, const ggd_scan_piggy* piggy, bool flag_flat_last) {
   if (n <= 0) return GGD_OK;
   const int passes = sort_passes(nbits);
   if (passes > RS_MAX_PASSES || (passes & 1)) return ggd_fail(ctx, GGD_E_INVALID, "sort32: need an even pass count");
@@ -602,7 +606,6 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
       hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, true, RS32_ITEMS, true>), dim3(ntiles + (pnb ? 1 : 0)),
                          dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 0, ghist, status, ntiles, gshift, tickets, n_valid,
                          2, pg);
-    if (p == 0 && pnb && total_ready) GGD_HIP(hipEventRecord(total_ready, s));   // num_rendered is on its way to the host
     if (p != 0)
       hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true>), dim3(ntiles + (p == 1 ? pnb : 0)),
                          dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 8 * p, ghist + p * RS_BINS,

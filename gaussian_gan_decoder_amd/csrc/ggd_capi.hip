@@ -123,10 +123,6 @@ extern "C" ggd_ctx* ggd_create(int device) {
     ctx->h_words_dev = nullptr;
     (void)hipGetLastError();
   }
-  if (ok && hipEventCreateWithFlags(&ctx->ev_r, hipEventDisableTiming) != hipSuccess) {
-    ctx->ev_r = nullptr;
-    (void)hipGetLastError();
-  }
   if (ok && (hipMalloc((void**)&ctx->sortctl, ggd_sort_ctrl_words() * sizeof(uint32_t)) != hipSuccess ||
              hipMemset(ctx->sortctl, 0, ggd_sort_ctrl_words() * sizeof(uint32_t)) != hipSuccess)) {
     ctx->sortctl = nullptr;
@@ -148,7 +144,6 @@ extern "C" void ggd_destroy(ggd_ctx* ctx) {
   if (ctx->h_words) (void)hipHostFree(ctx->h_words);
   if (ctx->sortctl) (void)hipFree(ctx->sortctl);
   if (ctx->scan_sums) (void)hipFree(ctx->scan_sums);
-  if (ctx->ev_r) (void)hipEventDestroy(ctx->ev_r);
   if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);
   if (ctx->dbg_vals) (void)hipFree(ctx->dbg_vals);
   for (int i = 0; i < 2 * ST_COUNT; ++i)
@@ -307,12 +302,30 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
 
 // Wait for the stream and publish R (the one host sync of a forward).
 static int geometry_finish(ggd_ctx* ctx, void* stream, const ggd_params* prm, int64_t* num_rendered) {
-  // The host needs num_rendered, not the finished frame: in the single-call forward it waits for the event behind the
-  // launch that delivered R (early in the depth sort) and returns while binning and blend are still running -- as
+  // The host needs num_rendered, not the finished frame: in the single-call forward it waits for the word written by the
+  // launch that delivers R (early in the depth sort) and returns while binning and blend are still running -- as
   // upstream returns with its render kernels in flight.  Outputs are ordered on the caller's stream as usual.
-  if (ctx->ev_r_pending) {
-    ctx->ev_r_pending = false;
-    GGD_HIP(hipEventSynchronize(ctx->ev_r));
+  if (ctx->r_pending) {
+    ctx->r_pending = false;
+    // the launch that carries the scan's block-sum step stores (tag << 32 | R) into the pinned mirror; poll for this
+    // call's tag (an event record behind that launch would cost the GPU a ~6 us bubble between two kernels).  Every few
+    // thousand polls the stream is queried: if it has drained without the tag (a failed launch), fall back to the copy.
+    volatile unsigned long long* slot = reinterpret_cast<volatile unsigned long long*>(ctx->h_words + 2);
+    const unsigned long long want = ctx->r_tag;
+    unsigned long long v = *slot;
+    for (unsigned spins = 0; (v >> 32) != want; ++spins) {
+      __builtin_ia32_pause();
+      if ((spins & 0xfff) == 0xfff && hipStreamQuery(static_cast<hipStream_t>(stream)) == hipSuccess) {
+        v = *slot;
+        if ((v >> 32) != want) {
+          GGD_HIP(hipMemcpy(ctx->h_words, ctx->d_words, sizeof(uint32_t), hipMemcpyDeviceToHost));
+          v = (want << 32) | ctx->h_words[0];
+        }
+        break;
+      }
+      v = *slot;
+    }
+    ctx->h_words[0] = (uint32_t)v;
   } else {
     GGD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   }
@@ -401,11 +414,13 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
         pg.in = tiles_w; pg.out = reinterpret_cast<uint32_t*>(const_cast<char*>(gb) + gv.point_offsets);
         pg.n = prm->P; pg.nb = ggd_scan_blocks(prm->P); pg.block_sums = ctx->scan_sums;
         pg.d_total = ctx->d_words; pg.h_total = ctx->h_words_dev;
+        pg.h_tagged = reinterpret_cast<unsigned long long*>(ctx->h_words_dev + 2);
+        pg.tag = ++ctx->r_tag;
       }
       const bool riding = ctx->scan_deferred;
       rc = ggd_launch_sort32_iota(ctx, s, depth_keys, ka, va, kb, vb, prm->P, 32, tmp, sort_tmp, clean_ctl,
-                                  riding ? &pg : nullptr, riding ? ctx->ev_r : nullptr, rowbin);
-      ctx->ev_r_pending = riding && ctx->ev_r != nullptr && rc == GGD_OK;
+                                  riding ? &pg : nullptr, rowbin);
+      ctx->r_pending = riding && rc == GGD_OK;
       ctx->scan_deferred = false;
       if (rc != GGD_OK) return rc;
     }

@@ -36,8 +36,8 @@ struct ggd_ctx {
   uint32_t* scan_sums = nullptr;    // block sums of a scan that rides on the depth sort (own allocation, grow-only)
   int scan_sums_cap = 0;
   bool scan_deferred = false;       // geometry_enqueue left the scan to the sort launches of the same call
-  hipEvent_t ev_r = nullptr;        // recorded right after the launch that delivers num_rendered (single-call forward)
-  bool ev_r_pending = false;        // ... and not yet waited for: the host waits for THAT, not for the end of the frame
+  uint32_t r_tag = 0;               // sequence number of the single-call forward whose num_rendered the host is waiting for
+  bool r_pending = false;           // the host waits for the tagged word (h_words[2..3]), not for the end of the frame
   void* dbg_keys = nullptr;     // debug copy of the unsorted list
   void* dbg_vals = nullptr;
   size_t dbg_cap = 0;
@@ -61,6 +61,9 @@ struct ggd_scan_piggy {
   uint32_t* block_sums = nullptr; // [nb] scratch
   uint32_t* d_total = nullptr;    // device word for the grand total (num_rendered)
   uint32_t* h_total = nullptr;    // device view of the pinned host word (may be NULL)
+  unsigned long long* h_tagged = nullptr;   // device view of a pinned 64-bit word that receives (tag << 32 | total): the host
+  uint32_t tag = 0;                         // polls it instead of waiting on an event (an event record between two kernels
+                                            // costs the GPU a ~6 us bubble)
 };
 
 int ggd_fail(ggd_ctx* ctx, int code, const std::string& msg);
@@ -119,7 +122,6 @@ int ggd_launch_sort(ggd_ctx* ctx, hipStream_t s, uint64_t* keys_a, uint32_t* val
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
                            uint32_t* clean_ctl = nullptr, const ggd_scan_piggy* piggy = nullptr,
-                           hipEvent_t total_ready = nullptr,    // recorded after the launch that writes piggy's total
                            bool flag_flat_last = false);        // a constant-digit LAST pass copies nothing: it sets the word
                                                                 // ggd_sort32_flat_ptr(ctl) and the result stays in (keys_b, vals_b)
 const uint32_t* ggd_sort32_flat_ptr(const void* ctl);

@@ -1,5 +1,5 @@
 import sys, os, math, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, cProfile, pstats
 from gaussian_gan_decoder_amd import rasterizer as R, _capi
 from gaussian_gan_decoder_amd.synthetic import make_scene
