@@ -227,13 +227,14 @@ __global__ __launch_bounds__(RB_THREADS) void rb_scatter1_kernel(const uint2* __
 }
 
 // level-2 block -> (row, chunk within the row)
+// (one load per lane + a ballot: a binary search over the table is six DEPENDENT global loads, which was most of a
+// level-2 workgroup's lifetime)
 __device__ __forceinline__ bool rb_block_row(const uint32_t* __restrict__ tab, uint32_t blk, int& row, uint32_t& chunk) {
-  if (blk >= tab[RB_TAB_ROWBLK + 64]) return false;
-  int r = 0;
-#pragma unroll
-  for (int step = 32; step >= 1; step >>= 1)
-    if (tab[RB_TAB_ROWBLK + r + step] <= blk) r += step;
-  row = r; chunk = blk - tab[RB_TAB_ROWBLK + r];
+  const uint32_t first = tab[RB_TAB_ROWBLK + (threadIdx.x & 63)];   // first block of row `lane` (non-decreasing)
+  const uint32_t total = tab[RB_TAB_ROWBLK + 64];
+  if (blk >= total) return false;
+  const int r = __popcll(__ballot(first <= blk)) - 1;               // last row that starts at or before blk
+  row = r; chunk = blk - (uint32_t)__shfl((int)first, r, 64);
   return true;
 }
 
