@@ -17,113 +17,7 @@
 
 namespace {
 
-// ------------------------------------------------------------------------------------------------ block scan --
-constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_ITEMS = 8;                        // per thread
-constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 per block
-
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = __shfl_up(v, d, 64);
-    if (lane >= d) v += o;
-  }
-  return v;
-}
-
-// Exclusive prefix of `v` over the 256 threads of the block (4 waves); *total = block sum.
-__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* total, uint32_t* lds4) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t inc = wave_inclusive_scan(v);
-  if (lane == 63) lds4[wv] = inc;
-  __syncthreads();
-  uint32_t base = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const uint32_t s = lds4[w];
-    if (w < wv) base += s;
-    tot += s;
-  }
-  __syncthreads();
-  *total = tot;
-  return base + inc - v;
-}
-
-// The three steps of the scan as workgroup-level functions: launched as their own kernels (two-call forward, sort path) or
-// run by EXTRA workgroups appended to the depth sort's first three launches (single-call forward: nothing on that path
-// reads the offsets or the total before the frame ends, so the scan needs no launches of its own -- see ggd_scan_piggy).
-__device__ __forceinline__ void scan_reduce_block(const uint32_t* __restrict__ in, int64_t n,
-                                                  uint32_t* __restrict__ block_sums, int blk, uint32_t* lds4) {
-  const int64_t base = (int64_t)blk * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
-  uint32_t s = 0;
-  if (base + SCAN_ITEMS <= n) {
-    const uint4 a = *reinterpret_cast<const uint4*>(in + base);
-    const uint4 b = *reinterpret_cast<const uint4*>(in + base + 4);
-    s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
-  } else {
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-      if (base + k < n) s += in[base + k];
-  }
-  uint32_t tot;
-  block_exclusive_scan_256(s, &tot, lds4);
-  if (threadIdx.x == 0) block_sums[blk] = tot;
-}
-
-// One workgroup turns block_sums[nb] into exclusive block prefixes (in place) and writes the grand total -- also straight
-// into the pinned host mirror (h_total: no blit kernel for the num_rendered read-back).
-__device__ __forceinline__ void scan_blocksums_block(uint32_t* __restrict__ block_sums, int nb,
-                                                     uint32_t* __restrict__ d_total, uint32_t* h_total, uint32_t* lds4,
-                                                     unsigned long long* h_tagged = nullptr, uint32_t tag = 0) {
-  uint32_t carry = 0;
-  for (int start = 0; start < nb; start += SCAN_THREADS) {
-    const int i = start + threadIdx.x;
-    const uint32_t v = i < nb ? block_sums[i] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block_exclusive_scan_256(v, &tot, lds4);
-    if (i < nb) block_sums[i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0 && d_total) *d_total = carry;
-  if (threadIdx.x == 0 && h_total) { *h_total = carry; __threadfence_system(); }
-  if (threadIdx.x == 0 && h_tagged) {   // one 64-bit store: the host sees tag and total together
-    __hip_atomic_store(h_tagged, ((unsigned long long)tag << 32) | carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
-template <bool EXCLUSIVE>
-__device__ __forceinline__ void scan_apply_block(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n,
-                                                 const uint32_t* __restrict__ block_prefix, int blk, uint32_t* lds4) {
-  const int64_t base = (int64_t)blk * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
-  uint32_t v[SCAN_ITEMS];
-  const bool full = base + SCAN_ITEMS <= n;
-  if (full) {
-    const uint4 a = *reinterpret_cast<const uint4*>(in + base);
-    const uint4 b = *reinterpret_cast<const uint4*>(in + base + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  } else {
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = (base + k < n) ? in[base + k] : 0u;
-  }
-  uint32_t s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) s += v[k];
-  uint32_t tot;
-  uint32_t run = block_exclusive_scan_256(s, &tot, lds4) + block_prefix[blk];
-  uint32_t o[SCAN_ITEMS];
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    if (EXCLUSIVE) { o[k] = run; run += v[k]; } else { run += v[k]; o[k] = run; }
-  }
-  if (full) {
-    *reinterpret_cast<uint4*>(out + base) = make_uint4(o[0], o[1], o[2], o[3]);
-    *reinterpret_cast<uint4*>(out + base + 4) = make_uint4(o[4], o[5], o[6], o[7]);
-  } else {
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-      if (base + k < n) out[base + k] = o[k];
-  }
-}
+#include "ggd_scan.inc"
 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const uint32_t* __restrict__ in, int64_t n,
                                                                    uint32_t* __restrict__ block_sums) {
@@ -571,7 +465,7 @@ size_t ggd_sort_ctrl_words() { return sort_ctrl_bytes() / sizeof(uint32_t); }
 
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
-                           uint32_t* clean_ctl, const ggd_scan_piggy* piggy, bool flag_flat_last) {
+                           uint32_t* clean_ctl, const ggd_scan_piggy* piggy, bool flag_flat_last, bool apply_here) {
   if (n <= 0) return GGD_OK;
   const int passes = sort_passes(nbits);
   if (passes > RS_MAX_PASSES || (passes & 1)) return ggd_fail(ctx, GGD_E_INVALID, "sort32: need an even pass count");
@@ -607,7 +501,7 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
                          dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 0, ghist, status, ntiles, gshift, tickets, n_valid,
                          2, pg);
     if (p != 0)
-      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true>), dim3(ntiles + (p == 1 ? pnb : 0)),
+      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true>), dim3(ntiles + ((p == 1 && apply_here) ? pnb : 0)),
                          dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 8 * p, ghist + p * RS_BINS,
                          status + (size_t)p * pass_words, ntiles, gshift, tickets + p, n_valid, 3, pg,
                          (flag_flat_last && p == passes - 1) ? tickets + RS_MAX_PASSES + 1 : nullptr);

@@ -402,13 +402,14 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
     void* tmp = sc + 4 * pairs;
     void* bin_tmp_ptr = sc + 4 * pairs + sort_tmp;  // the sort's histogram block stays alive for the binning pass
     uint32_t* clean_ctl = nullptr;
+    ggd_scan_piggy pg;          // a scan that rides on this call's launches (see geometry_enqueue)
+    bool riding = false;
     {
       StageTimer t(ctx, ST_SORT, s);
       // the control block this frame's scan cleared, if nobody has used it since (a second render of the same geometry
       // falls back to the memset)
       clean_ctl = ctx->sortctl_clean ? ctx->sortctl : nullptr;
       ctx->sortctl_clean = false;
-      ggd_scan_piggy pg;
       if (ctx->scan_deferred) {   // this call's geometry half left the scan to us
         uint32_t* tiles_w = reinterpret_cast<uint32_t*>(const_cast<char*>(gb) + gv.tiles_touched);
         pg.in = tiles_w; pg.out = reinterpret_cast<uint32_t*>(const_cast<char*>(gb) + gv.point_offsets);
@@ -417,9 +418,9 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
         pg.h_tagged = reinterpret_cast<unsigned long long*>(ctx->h_words_dev + 2);
         pg.tag = ++ctx->r_tag;
       }
-      const bool riding = ctx->scan_deferred;
+      riding = ctx->scan_deferred;
       rc = ggd_launch_sort32_iota(ctx, s, depth_keys, ka, va, kb, vb, prm->P, 32, tmp, sort_tmp, clean_ctl,
-                                  riding ? &pg : nullptr, rowbin);
+                                  riding ? &pg : nullptr, rowbin, !rowbin);
       ctx->r_pending = riding && rc == GGD_OK;
       ctx->scan_deferred = false;
       if (rc != GGD_OK) return rc;
@@ -430,7 +431,7 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
       const uint32_t* n_vis = ggd_sort32_nvalid_ptr(clean_ctl ? static_cast<const void*>(clean_ctl) : tmp);
       const void* ctl = clean_ctl ? static_cast<const void*>(clean_ctl) : tmp;
       rc = rowbin ? ggd_launch_rowbin(ctx, s, *prm, rect, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp, vb,
-                                      ggd_sort32_flat_ptr(ctl))
+                                      ggd_sort32_flat_ptr(ctl), riding ? &pg : nullptr)
                   : ggd_launch_tilebin(ctx, s, *prm, rect, tiles, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp);
       if (rc != GGD_OK) return rc;
     }

@@ -122,7 +122,8 @@ int ggd_launch_sort(ggd_ctx* ctx, hipStream_t s, uint64_t* keys_a, uint32_t* val
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
                            uint32_t* clean_ctl = nullptr, const ggd_scan_piggy* piggy = nullptr,
-                           bool flag_flat_last = false);        // a constant-digit LAST pass copies nothing: it sets the word
+                           bool flag_flat_last = false, bool apply_here = true);   // apply_here = false: the caller runs the
+                           // scan's last step (offsets) elsewhere -- ggd_launch_rowbin(apply = ...)        // a constant-digit LAST pass copies nothing: it sets the word
                                                                 // ggd_sort32_flat_ptr(ctl) and the result stays in (keys_b, vals_b)
 const uint32_t* ggd_sort32_flat_ptr(const void* ctl);
 // Tile binning (GGD_OPT_BINNING = 1): sorted Gaussian order -> per-tile lists + ranges.
@@ -130,7 +131,9 @@ bool ggd_rowbin_supported(int W, int H);
 size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity);
 int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect, const uint32_t* order,
                       const uint32_t* n_vis_ptr, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
-                      size_t tmp_bytes, const uint32_t* order_alt = nullptr, const uint32_t* use_alt = nullptr);
+                      size_t tmp_bytes, const uint32_t* order_alt = nullptr, const uint32_t* use_alt = nullptr,
+                      const ggd_scan_piggy* apply = nullptr);   // apply: step 3 of a riding scan, as appended workgroups of the
+                                                                 // last (longest) binning launch
                       // *use_alt != 0 (device): the depth order is in order_alt (see ggd_launch_sort32_iota)
 bool ggd_tilebin_supported(int T);
 size_t ggd_tilebin_tmp_bytes(int P, int T);

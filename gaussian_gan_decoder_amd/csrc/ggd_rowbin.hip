@@ -16,6 +16,8 @@
 
 namespace {
 
+#include "ggd_scan.inc"
+
 constexpr int RB_THREADS = 256;
 constexpr int RB_WAVES = RB_THREADS / 64;
 constexpr int RB_STAGE = 4096;                     // instances a level-2 workgroup can stage in LDS (16 KB; measured: 4096 / 6144 /
@@ -319,10 +321,15 @@ __global__ __launch_bounds__(1024) void rb_scan2_kernel(uint32_t* __restrict__ c
 __global__ __launch_bounds__(RB_THREADS) void rb_scatter2_kernel(const uint2* __restrict__ ent, uint32_t ent_cap,
                                                                  const uint32_t* __restrict__ tab,
                                                                  const uint32_t* __restrict__ prefix2,
-                                                                 uint32_t* __restrict__ list, uint32_t capacity) {
+                                                                 uint32_t* __restrict__ list, uint32_t capacity,
+                                                                 uint32_t main_blocks, ggd_scan_piggy pg) {
   __shared__ int diff[RB_WAVES][65];
   __shared__ uint32_t wcnt[RB_WAVES][64];
   __shared__ uint32_t stage[RB_STAGE];
+  if (blockIdx.x >= main_blocks) {   // appended workgroups: last step of the offsets scan (see ggd_scan_piggy)
+    scan_apply_block<false>(pg.in, pg.out, pg.n, pg.block_sums, (int)(blockIdx.x - main_blocks), stage);
+    return;
+  }
   int row; uint32_t chunk;
   if (!rb_block_row(tab, blockIdx.x, row, chunk)) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -392,7 +399,7 @@ size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity) {
 // capacity: upper bound on num_rendered (the level-1 entry count is <= num_rendered); order = depth-sorted ids.
 int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect, const uint32_t* order,
                       const uint32_t* n_vis_ptr, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
-                      size_t tmp_bytes, const uint32_t* order_alt, const uint32_t* use_alt) {
+                      size_t tmp_bytes, const uint32_t* order_alt, const uint32_t* use_alt, const ggd_scan_piggy* apply) {
   if (!ggd_rowbin_supported(prm.width, prm.height)) return ggd_fail(ctx, GGD_E_INVALID, "tile grid too large for row binning");
   if (tmp_bytes < ggd_rowbin_tmp_bytes(prm.P, capacity)) return ggd_fail(ctx, GGD_E_INVALID, "rowbin tmp too small");
   const int gx = (prm.width + 15) / 16, gy = (prm.height + 15) / 16;
@@ -411,7 +418,9 @@ int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const 
                      ent, capacity);
   hipLaunchKernelGGL(rb_count2_kernel, dim3(nb2), dim3(RB_THREADS), 0, s, ent, capacity, tab, counts2);
   hipLaunchKernelGGL(rb_scan2_kernel, dim3(gy), dim3(1024), 0, s, counts2, tab, gx, gy, ranges);
-  hipLaunchKernelGGL(rb_scatter2_kernel, dim3(nb2), dim3(RB_THREADS), 0, s, ent, capacity, tab, counts2, list, capacity);
+  static_assert(RB_THREADS == SCAN_THREADS, "the appended scan workgroups share the launch's block size");
+  hipLaunchKernelGGL(rb_scatter2_kernel, dim3(nb2 + (apply ? (uint32_t)apply->nb : 0u)), dim3(RB_THREADS), 0, s, ent, capacity,
+                     tab, counts2, list, capacity, nb2, apply ? *apply : ggd_scan_piggy{});
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }
