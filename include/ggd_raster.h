@@ -149,9 +149,12 @@ int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* prm,
                        void* binning_buf, void* img_buf, float* out_color);
 
 /*
- * Forward in ONE call with a caller-chosen binning capacity (instances): geometry + render are enqueued back to back
- * and the host waits once at the end, so the GPU does not idle while num_rendered travels to the host (the two-phase
- * form above stalls the stream for that round trip).  binning_buf must hold ggd_binning_bytes(capacity).  Returns
+ * Forward in ONE call with a caller-chosen binning capacity (instances): geometry + render are enqueued back to back,
+ * so the GPU does not idle while num_rendered travels to the host (the two-phase form above stalls the stream for that
+ * round trip).  On the speculative route the call returns as soon as num_rendered has ARRIVED -- the binning and blend
+ * kernels may still be running: out_color and the buffers are ordered on `stream` like the result of any asynchronous
+ * launch (upstream's forward likewise returns with its render kernels in flight); synchronise the stream before reading
+ * them from the host or from another stream.  binning_buf must hold ggd_binning_bytes(capacity).  Returns
  * GGD_E_CAPACITY (with *num_rendered set) when capacity < num_rendered: call again with a larger buffer.  ggd_backward
  * takes the returned num_rendered (the sorted list is at offset 0 of binning_buf for every capacity).  ggd_forward_can_speculate
  * tells whether the call will take the speculative route (tile-binning path) for that capacity.
