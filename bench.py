@@ -425,7 +425,7 @@ def main():
                     "scenes_per_gpu": spg, "points_per_scene": args.train_points, "image": "512x512",
                     "parameters_all_reduced": nparam, "allreduce_bytes": ar,
                     "stand_ins": ("backbone gradient payload (%d floats) + LPIPS slot (fixed random VGG16-shaped trunk at "
-                                  "256x256, weight 1.0)" % BACKBONE_REST) if standins else "none (round-1 configuration)"}
+                                  "256x256 on the batch of rendered images and on the batch of targets, weight 1.0)" % BACKBONE_REST) if standins else "none (round-1 configuration)"}
 
         LOSS = "L1+L2+SSIM+Sobel (fused HIP loss, reference weights) + perceptual stand-in (PyTorch convs)"
         # (1) the reference's precision: decoder MLPs in fp32 (PyTorch GEMMs, split-K weight gradients)

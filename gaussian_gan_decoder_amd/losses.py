@@ -60,7 +60,8 @@ def fused_image_loss(image, target, l1_weight=0.2, l2_weight=0.1, ssim_weight=0.
 
 class PerceptualStandIn(torch.nn.Module):
     """perc(target, image) of main/loss_utils/lpips.py:16-34 with a fixed random VGG16-shaped trunk (see the module
-    docstring).  forward(image [3,H,W] in [0,1], target [3,H,W]) -> scalar; gradients flow into `image` only."""
+    docstring).  forward(image [3,H,W] or [B,3,H,W] in [0,1], target likewise) -> scalar (summed over the batch, as the
+    reference evaluates the whole batch in one VGG call); gradients flow into `image` only."""
     CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512)
     TAPS = (1, 3, 6, 9, 12)       # index of the convolution after whose ReLU a feature map is taken
 
@@ -84,7 +85,7 @@ class PerceptualStandIn(torch.nn.Module):
         self.requires_grad_(False)
 
     def features(self, img):
-        x = (img.unsqueeze(0) * 2.0 - 1.0)
+        x = ((img if img.dim() == 4 else img.unsqueeze(0)) * 2.0 - 1.0)
         if x.shape[2] > 256:
             x = F.interpolate(x, size=(256, 256), mode="area")     # lpips.py:23-26
         feats, ci = [], 0

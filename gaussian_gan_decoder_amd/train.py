@@ -221,7 +221,9 @@ class DecoderTrainer:
         target = batch.target[b]
         loss = self.loss_fn(image, target, **self.loss_w)[0]
         if self.perceptual is not None:
-            loss = loss + self.perceptual_weight * self.perceptual(image, target)
+            # the reference evaluates its perceptual network on the whole batch at once (lpips.py:29-31): the rendered
+            # images are collected and local_loss makes ONE call on the stack
+            self._perc_images.append(image)
         return loss
 
     def local_loss(self, batch: SceneBatch):
@@ -234,6 +236,7 @@ class DecoderTrainer:
             attrs = split_attrs(self.decoder_fwd.forward_scenes(
                 [self.planes * self.latents[s][None, :, None, None] for s in scene_ids], batch.positions))
         losses = []
+        self._perc_images = []
         if self.use_streams and B > 1:
             main = torch.cuda.current_stream(self.device)
             while len(self._streams) < B:
@@ -252,6 +255,9 @@ class DecoderTrainer:
         total = losses[0]
         for l in losses[1:]:
             total = total + l
+        if self.perceptual is not None:
+            total = total + self.perceptual_weight * self.perceptual(torch.stack(self._perc_images), batch.target[:B])
+            self._perc_images = []
         total = total / B
         if self.backbone is not None:
             total = total + 1e-8 * torch.dot(self.backbone, self.backbone_probe)
