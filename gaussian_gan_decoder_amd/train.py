@@ -158,7 +158,9 @@ class DecoderTrainer:
         if cur_params:
             self.buckets.append((cur_start, off, cur_params))
         # an all-reduce chunk never exceeds BUCKET_BYTES: slice large buckets (one big parameter) for the collective only
-        self.optims = [torch.optim.Adam([{"params": ps, "lr": lr}]) for _, _, ps in self.buckets]
+        # one fused Adam kernel per bucket on the GPU (the default foreach form makes ~10 passes over the 119 MB of parameters)
+        fused = torch.device(self.device).type == "cuda"
+        self.optims = [torch.optim.Adam([{"params": ps, "lr": lr}], fused=fused) for _, _, ps in self.buckets]
 
     @property
     def world(self):
