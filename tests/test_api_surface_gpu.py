@@ -180,3 +180,31 @@ def test_two_streams_render_concurrently(native_lib):
             assert torch.equal(c.detach().cpu(), c0)
             # the backward's float atomics are unordered: same tolerance class as two runs on one stream
             assert (leaf.grad.detach().cpu() - g0).abs().max() <= 1e-4 * max(1.0, float(g0.abs().max()))
+
+
+def test_back_to_back_forwards_do_not_disturb_each_other(native_lib):
+    """The single-call forward returns when num_rendered has arrived, with binning and blend possibly still running.  Three
+    different scenes (same shape, so the later calls take the single-call route and share the context's scratch) are
+    rendered back to back without any synchronisation in between; every result must equal the scene rendered alone."""
+    from _util import scene_inputs, run_native
+    dev = torch.device("cuda:0")
+    scenes = [scene_inputs(P=300000, size=512, seed=s, lsm=-5.5) for s in (11, 12, 13)]
+    alone = []
+    for d in scenes:
+        n = run_native(d, debug=False)     # first call of the shape: two-call form; later ones: single-call
+        torch.cuda.synchronize(dev)
+        alone.append((n["num_rendered"], n["color"].clone(), n["point_list"].copy()))
+    from gaussian_gan_decoder_amd import rasterizer as R
+    t = lambda x: torch.empty(0, device=dev) if x is None else x.to(dev)
+    args = [(t(d["bg"]), t(d["means3D"]), t(d["colors_precomp"]), t(d["opacities"]), t(d["scales"]), t(d["rotations"]),
+             d["scale_modifier"], t(d["cov3D_precomp"]), t(d["viewmatrix"]), t(d["projmatrix"]), d["tanfovx"], d["tanfovy"],
+             d["H"], d["W"], t(d["shs"]), d["sh_degree"], t(d["campos"]), False, False) for d in scenes]
+    torch.cuda.synchronize(dev)
+    for rep in range(3):
+        outs = [R.rasterize_gaussians_native(*a) for a in args]      # no sync between the calls
+        torch.cuda.synchronize(dev)
+        for (Rn, color, radii, geom, binning, img), (R0, c0, l0) in zip(outs, alone):
+            assert Rn == R0
+            assert torch.equal(color, c0)
+            lst = binning.cpu().numpy()[:4 * Rn].view(np.uint32)       # the list sits at offset 0 of the binning buffer
+            np.testing.assert_array_equal(lst, l0)
