@@ -111,9 +111,7 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* __restrict__ w, 
       acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bin[0][s], acc[0][mt], 0, 0, 0);
       acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bin[1][s], acc[1][mt], 0, 0, 0);
     }
-#ifndef GGD_MLP_NO_SCHED_BARRIER
     __builtin_amdgcn_sched_barrier(0);  // keep the weight reads of later tiles from being hoisted (VGPR pressure)
-#endif
   }
 }
 
