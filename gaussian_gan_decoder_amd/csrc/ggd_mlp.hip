@@ -100,18 +100,36 @@ template <int KB /* 32-wide k blocks */, int ROW>
 __device__ __forceinline__ void layer_mfma(const unsigned char* __restrict__ w, const float* __restrict__ bias,
                                            const bf16x8 (&bin)[2][4], f4 (&acc)[2][8], int lane) {
   const int i = lane & 15, g = lane >> 4;
+  // The weight fragments of feature tile mt + 1 are requested from LDS before the MFMAs of tile mt are issued (one tile of
+  // look-ahead, KB extra 16-byte registers): with the reads and their MFMAs in the same scheduling region every tile
+  // waited out the LDS latency (~200 cycles x 8 tiles x 3 layers per slab and head).
+  bf16x8 a_cur[KB], a_nxt[KB];
+  f4 b_cur, b_nxt;
+  {
+    const unsigned char* row = w + (size_t)i * ROW + g * 16;
+#pragma unroll
+    for (int s = 0; s < KB; ++s) a_cur[s] = *reinterpret_cast<const bf16x8*>(row + s * 64);
+    b_cur = *reinterpret_cast<const f4*>(bias + 4 * g);
+  }
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
-    const f4 b4 = *reinterpret_cast<const f4*>(bias + 16 * mt + 4 * g);  // D rows 4g..4g+3 of this feature tile
-    acc[0][mt] = b4; acc[1][mt] = b4;
-    const unsigned char* row = w + (size_t)(16 * mt + i) * ROW + g * 16;
+    if (mt + 1 < 8) {
+      const unsigned char* row = w + (size_t)(16 * (mt + 1) + i) * ROW + g * 16;
+#pragma unroll
+      for (int s = 0; s < KB; ++s) a_nxt[s] = *reinterpret_cast<const bf16x8*>(row + s * 64);
+      b_nxt = *reinterpret_cast<const f4*>(bias + 16 * (mt + 1) + 4 * g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    acc[0][mt] = b_cur; acc[1][mt] = b_cur;   // D rows 4g..4g+3 of this feature tile start from the bias
 #pragma unroll
     for (int s = 0; s < KB; ++s) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(row + s * 64);
-      acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bin[0][s], acc[0][mt], 0, 0, 0);
-      acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bin[1][s], acc[1][mt], 0, 0, 0);
+      acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[s], bin[0][s], acc[0][mt], 0, 0, 0);
+      acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[s], bin[1][s], acc[1][mt], 0, 0, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);  // keep the weight reads of later tiles from being hoisted (VGPR pressure)
+    __builtin_amdgcn_sched_barrier(0);  // keep the reads of later tiles from being hoisted further (VGPR pressure)
+#pragma unroll
+    for (int s = 0; s < KB; ++s) a_cur[s] = a_nxt[s];
+    b_cur = b_nxt;
   }
 }
 
