@@ -198,3 +198,24 @@ def test_collisions_and_degenerate_members(native_lib):
         same = n["n_contrib"] == o["n_contrib"]
         assert (~same).sum() <= 1
         assert np.abs(n["color"].cpu().numpy() - o["color"])[:, same].max() <= RGB_ATOL
+
+
+@pytest.mark.parametrize("P", [1, 63, 2047, 2048, 2049, 4095, 4096, 4097, 8193, 12289])
+def test_single_call_forward_at_block_boundaries(native_lib, P):
+    """Sizes around the workgroup granularities of the scan (2048), the depth sort (4096) and the binning chunks (1024): the
+    single-call forward (scan steps riding on the sort / binning launches, num_rendered polled from the pinned word) must
+    reproduce the two-call forward and the oracle bit for bit."""
+    from gaussian_gan_decoder_amd import _capi
+    d = scene_inputs(P=P, size=96, lsm=-4.5, seed=100 + P, width=96, height=80)
+    ctx = _capi.context_for(torch.device("cuda:0"))
+    ctx.capacity_hint.pop((P, 96, 80), None)
+    o = run_oracle(d)
+    first = run_native(d, debug=False)        # no hint yet: two-call form
+    second = run_native(d, debug=False)       # hint: single-call form
+    for n in (first, second):
+        assert n["num_rendered"] == o["num_rendered"]
+        np.testing.assert_array_equal(n["tiles_touched"], o["tiles_touched"])
+        np.testing.assert_array_equal(n["point_offsets"], o["point_offsets"])
+        np.testing.assert_array_equal(n["point_list"], o["point_list"])
+        np.testing.assert_array_equal(n["ranges"], o["ranges"])
+    assert torch.equal(first["color"], second["color"])
