@@ -244,6 +244,8 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
   if (rc != GGD_OK) return rc;
   if (!num_rendered) return ggd_fail(ctx, GGD_E_INVALID, "num_rendered is NULL");
   *num_rendered = 0;
+  ctx->r_pending = false;      // (a previous call that failed half way may have left these set)
+  ctx->scan_deferred = false;
   if (prm->P == 0) return GGD_OK;
   if (!geom_buf || !radii || !opacities) return ggd_fail(ctx, GGD_E_INVALID, "geom_buf / radii / opacities is NULL");
   if (prm->raw_attributes && cov3D_precomp)
