@@ -320,13 +320,18 @@ static int geometry_finish(ggd_ctx* ctx, void* stream, const ggd_params* prm, in
     unsigned long long v = *slot;
     for (unsigned spins = 0; (v >> 32) != want; ++spins) {
       __builtin_ia32_pause();
-      if ((spins & 0xfff) == 0xfff && hipStreamQuery(static_cast<hipStream_t>(stream)) == hipSuccess) {
-        v = *slot;
-        if ((v >> 32) != want) {
-          GGD_HIP(hipMemcpy(ctx->h_words, ctx->d_words, sizeof(uint32_t), hipMemcpyDeviceToHost));
-          v = (want << 32) | ctx->h_words[0];
+      if ((spins & 0xfff) == 0xfff) {
+        const hipError_t q = hipStreamQuery(static_cast<hipStream_t>(stream));
+        if (q == hipSuccess) {
+          v = *slot;
+          if ((v >> 32) != want) {
+            GGD_HIP(hipMemcpy(ctx->h_words, ctx->d_words, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            v = (want << 32) | ctx->h_words[0];
+          }
+          break;
         }
-        break;
+        if (q != hipErrorNotReady)   // the stream is in an error state: do not spin on a word that will never come
+          return ggd_fail(ctx, GGD_E_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
       }
       v = *slot;
     }
