@@ -203,19 +203,37 @@ class Decoder(nn.Module):
         return self.backbone(torch.concat([feats, gaussian_features], dim=-1))
 
 
+def embed_positions(x: torch.Tensor, num_freqs: int = 10, include_input: bool = True) -> torch.Tensor:
+    """Positional encoding of main/decoder_utils/pos_encoding.py (the decoders' use_xyz_embedding option): [x,
+    sin(f x), cos(f x) for f in linspace(2^0, 2^(num_freqs - 1), num_freqs)] concatenated on the last axis ->
+    3 + 3 * 2 * num_freqs = 63 columns for the reference's settings (frequencies spaced LINEARLY, as the reference's
+    default log_sampling=False gives)."""
+    freqs = torch.linspace(2.0 ** 0.0, 2.0 ** (num_freqs - 1), steps=num_freqs, dtype=x.dtype, device=x.device)
+    parts = [x] if include_input else []
+    for f in freqs:
+        parts += [torch.sin(x * f), torch.cos(x * f)]
+    return torch.cat(parts, -1)
+
+
+def _info_dim(position_dim: int, use_xyz_embedding: bool, num_freqs: int = 10) -> int:
+    if position_dim != 3:
+        raise ValueError("positions are 3-vectors")
+    return 3 + 3 * 2 * num_freqs if use_xyz_embedding else 3
+
+
 class SequentialDecoderReverse(nn.Module):
     """Feature planes + positions -> raw Gaussian attributes (xyz, scale, rotation, opacity, color)."""
 
     def __init__(self, plane_channels=32, hidden_dim=128, position_dim=3, box_warp=1.0, plane_axes="eg3d",
-                 triplane_depth=None):
+                 triplane_depth=None, use_xyz_embedding=False):
         """plane_axes / triplane_depth: which generator produced the planes -- "eg3d", None: EG3D tri-planes [3, 32, H, W];
         "panohead", D: PanoHead tri-grids [3, 32 * D, H, W] (G.rendering_kwargs["triplane_depth"],
-        sequential_decoder_reverse.py:42-50).  position_dim must be 3: the reference's optional positional encoding
-        (use_xyz_embedding, default off in main/train_pano2gaussian_decoder.py:46) is not implemented."""
+        sequential_decoder_reverse.py:42-50).  use_xyz_embedding: the reference's optional positional encoding of the
+        positions (sequential_decoder_reverse.py:21-22,63-66; off by default in main/train_pano2gaussian_decoder.py:46);
+        PyTorch modules only -- the fused MFMA decoder takes the 3-vector form."""
         super().__init__()
-        if position_dim != 3:
-            raise NotImplementedError("positional encoding of the positions (use_xyz_embedding) is not implemented")
-        f = plane_channels + position_dim
+        self.use_xyz_embedding = bool(use_xyz_embedding)
+        f = plane_channels + _info_dim(position_dim, self.use_xyz_embedding)
         self.box_warp = box_warp
         self.plane_axes = plane_axes
         self.triplane_depth = triplane_depth
@@ -232,7 +250,7 @@ class SequentialDecoderReverse(nn.Module):
     def forward(self, feature_planes, init_position):
         # the 5 heads all average the three planes' samples
         pf = triplane_mean(feature_planes, init_position, self.box_warp, self.plane_axes, self.triplane_depth)
-        info = init_position
+        info = embed_positions(init_position) if self.use_xyz_embedding else init_position
         color = self.color_decoder(pf, info)
         info = torch.concat([info, color], dim=-1)
         opacity = self.opacity_decoder(pf, info)
@@ -258,11 +276,10 @@ class SequentialDecoder(nn.Module):
     activation -softplus(s + 5) - 2 (NOT -2.5 as in the reversed chain).  Same parameter names as the reference."""
 
     def __init__(self, plane_channels=32, hidden_dim=128, position_dim=3, box_warp=1.0, plane_axes="eg3d",
-                 triplane_depth=None):
+                 triplane_depth=None, use_xyz_embedding=False):
         super().__init__()
-        if position_dim != 3:
-            raise NotImplementedError("positional encoding of the positions (use_xyz_embedding) is not implemented")
-        f = plane_channels + position_dim
+        self.use_xyz_embedding = bool(use_xyz_embedding)
+        f = plane_channels + _info_dim(position_dim, self.use_xyz_embedding)
         self.box_warp, self.plane_axes, self.triplane_depth = box_warp, plane_axes, triplane_depth
         self.xyz_decoder = Decoder(f, 3, hidden_dim)
         self.scale_decoder = Decoder(f + 3, 3, hidden_dim)
@@ -276,7 +293,7 @@ class SequentialDecoder(nn.Module):
 
     def forward(self, feature_planes, init_position):
         pf = triplane_mean(feature_planes, init_position, self.box_warp, self.plane_axes, self.triplane_depth)
-        info = init_position
+        info = embed_positions(init_position) if self.use_xyz_embedding else init_position
         xyz = self.xyz_decoder(pf, info) * 0.01 + init_position
         info = torch.concat([info, xyz], dim=-1)
         scale = self.activate_scale(self.scale_decoder(pf, info))
@@ -296,11 +313,10 @@ class ParallelDecoder(nn.Module):
     "parallel"); scale activation -softplus(s + 5) - 2."""
 
     def __init__(self, plane_channels=32, hidden_dim=128, position_dim=3, box_warp=1.0, plane_axes="eg3d",
-                 triplane_depth=None):
+                 triplane_depth=None, use_xyz_embedding=False):
         super().__init__()
-        if position_dim != 3:
-            raise NotImplementedError("positional encoding of the positions (use_xyz_embedding) is not implemented")
-        f = plane_channels + position_dim
+        self.use_xyz_embedding = bool(use_xyz_embedding)
+        f = plane_channels + _info_dim(position_dim, self.use_xyz_embedding)
         self.box_warp, self.plane_axes, self.triplane_depth = box_warp, plane_axes, triplane_depth
         self.xyz_decoder = Decoder(f, 3, hidden_dim)
         self.scale_decoder = Decoder(f, 3, hidden_dim)
@@ -314,7 +330,7 @@ class ParallelDecoder(nn.Module):
 
     def forward(self, feature_planes, init_position):
         pf = triplane_mean(feature_planes, init_position, self.box_warp, self.plane_axes, self.triplane_depth)
-        pos = init_position
+        pos = embed_positions(init_position) if self.use_xyz_embedding else init_position
         return SimpleNamespace(xyz=self.xyz_decoder(pf, pos) * 0.01 + init_position,
                                scale=self.activate_scale(self.scale_decoder(pf, pos)),
                                rotation=self.rotation_decoder(pf, pos), opacity=self.opacity_decoder(pf, pos),

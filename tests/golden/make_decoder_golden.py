@@ -75,7 +75,15 @@ def main():
                             opacity=o2.opacity.numpy(), rotation=o2.rotation.numpy(), scale=o2.scale.numpy(),
                             xyz=o2.xyz.numpy(), **sd2)
         print(f"wrote {tag}_decoder_fixture.npz")
-
+    # The positional encoding of the positions (use_xyz_embedding; main/decoder_utils/pos_encoding.py).  The reference's
+    # decoder classes cannot be CONSTRUCTED with use_xyz_embedding=True in this environment -- their
+    # torch_utils.persistence decorator pickles the constructor arguments' object graph and the Embedder holds local
+    # closures ("Can't pickle local object 'Embedder.frequency_activation.<locals>.func'") -- so the fixture pins the
+    # Embedder itself, with the settings the decoders give it (sequential_decoder_reverse.py:22).
+    from main.decoder_utils.pos_encoding import Embedder
+    emb = Embedder(include_input=True, input_dims=3, num_freqs=10)(pos)
+    np.savez_compressed(os.path.join(HERE, "position_embedding_fixture.npz"), positions=pos.numpy(), embedding=emb.numpy())
+    print("wrote position_embedding_fixture.npz; embedding", tuple(emb.shape))
 
 if __name__ == "__main__":
     main()

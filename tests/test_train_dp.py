@@ -134,3 +134,22 @@ def test_other_decoder_types_match_reference_class_fixtures(tag):
     for k in ("color", "opacity", "rotation", "scale", "xyz"):
         np.testing.assert_allclose(getattr(out, k).numpy(), f[k], atol=2e-5, rtol=1e-5, err_msg=k)
     assert (out.scale <= -2.0).all()
+
+
+def test_position_embedding_matches_the_reference_embedder():
+    """use_xyz_embedding: embed_positions == the reference's Embedder(include_input=True, input_dims=3, num_freqs=10)
+    (main/decoder_utils/pos_encoding.py) on seeded positions; the three decoder classes accept the 63-column form."""
+    from gaussian_gan_decoder_amd.decoder import embed_positions, SequentialDecoderReverse, SequentialDecoder, ParallelDecoder
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "position_embedding_fixture.npz"))
+    pos = torch.from_numpy(f["positions"])
+    e = embed_positions(pos)
+    assert e.shape == (pos.shape[0], 63)
+    np.testing.assert_allclose(e.numpy(), f["embedding"], atol=1e-6, rtol=0)
+    torch.manual_seed(3)
+    planes = torch.randn(3, 32, 16, 16)
+    for cls in (SequentialDecoderReverse, SequentialDecoder, ParallelDecoder):
+        dec = cls(use_xyz_embedding=True)
+        assert dec.color_decoder.backbone[0].in_features in (32 + 63, 32 + 63 + 11)
+        out = dec(planes, pos)
+        assert out.xyz.shape == (pos.shape[0], 3) and torch.isfinite(out.color).all()
+        out.xyz.sum().backward()
