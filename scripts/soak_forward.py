@@ -1,0 +1,31 @@
+"""Soak test of the single-call forward: thousands of frames alternating between scenes of different sizes on one stream, with
+the returned num_rendered and a checksum of the image checked every frame against the first rendering of that scene."""
+import sys, os, math, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gaussian_gan_decoder_amd import rasterizer as R
+from gaussian_gan_decoder_amd.synthetic import make_scene
+dev = torch.device('cuda:0')
+def args_for(P, S, kind, seed):
+    sc = make_scene(P, S, kind, seed=seed).to(dev); cam = sc.cam; e = torch.empty(0, device=dev)
+    return (sc.bg, sc.xyz, e, sc.opacities.contiguous(), sc.scales.contiguous(), sc.rotations.contiguous(), 1.0, e, cam.world_view_transform,
+            cam.full_proj_transform, math.tan(cam.FoVx*0.5), math.tan(cam.FoVy*0.5), S, S, sc.features_dc.contiguous(), 0, cam.camera_center, False, False)
+scenes = [args_for(200000, 512, 'cube', 1), args_for(50000, 256, 'shell', 2), args_for(1000000, 1024, 'cube', 0), args_for(3000, 128, 'cube', 3)]
+ref = []
+for a in scenes:
+    for _ in range(2): out = R.rasterize_gaussians_native(*a)
+    torch.cuda.synchronize(); ref.append((out[0], out[1].double().sum().item(), out[1].clone()))
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+t = time.perf_counter(); bad = 0; pend = []
+for it in range(n):
+    k = (it * 7 + it // 5) % len(scenes)
+    out = R.rasterize_gaussians_native(*scenes[k])
+    if out[0] != ref[k][0]: bad += 1
+    pend.append((k, out[1]))
+    if len(pend) == 16:      # image checks in batches, so that most frames run without an intervening sync
+        for kk, img in pend:
+            if not torch.equal(img, ref[kk][2]): bad += 1
+        pend = []
+torch.cuda.synchronize()
+print("frames", n, "mismatches", bad, "seconds", round(time.perf_counter() - t, 2))
+sys.exit(1 if bad else 0)
