@@ -116,8 +116,12 @@ extern "C" ggd_ctx* ggd_create(int device) {
   (void)hipGetDevice(&prev);
   bool ok = hipSetDevice(device) == hipSuccess &&
             hipMalloc((void**)&ctx->d_words, 256) == hipSuccess &&
-            hipHostMalloc((void**)&ctx->h_words, 64, hipHostMallocDefault) == hipSuccess &&
+            // coherent (fine-grained) pinned memory: the tagged num_rendered word must become visible to the polling host
+            // while the kernel that stored it is still running, whatever HIP_HOST_COHERENT says
+            hipHostMalloc((void**)&ctx->h_words, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess &&
             hipMemset(ctx->d_words, 0, 256) == hipSuccess;
+  // stale pinned memory (e.g. of a destroyed context) must never match a tag: r_tag restarts at 1 for every context
+  if (ok) memset(ctx->h_words, 0, 64);
   for (int i = 0; ok && i < 2 * ST_COUNT; ++i) ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
   // device-side view of the pinned mirror (the scan writes num_rendered there itself: no blit for the read-back) and the
   // depth sort's control block in its own allocation (cleared by the scan: no memset launch in front of the sort);

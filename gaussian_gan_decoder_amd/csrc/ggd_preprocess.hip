@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         // grows with the anisotropy of Q) + 0.01 px.  Indefinite / NaN conics get +inf (never culled by the box);
         // thr > 0 (opacity < 1/255) can never be reached by power <= 0: the box is empty (extents -inf).
         const float L = logf(1.0f / (255.0f * opac));
-        const float thr = L - (2e-5f + 1e-6f * fabsf(L));
+        float thr = L - (2e-5f + 1e-6f * fabsf(L));
         const float cdet = conA * conC - conB * conB;
         const float tau2 = -2.0f * thr;
         float ex = __builtin_huge_valf(), ey = __builtin_huge_valf();
@@ -123,6 +123,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
           ey = __builtin_sqrtf(fmaxf(sdet * conA, 0.0f)) * infl + 0.01f;
         }
         if (tau2 < 0.0f) { ex = -__builtin_huge_valf(); ey = -__builtin_huge_valf(); }
+        // opacity <= 0 (or NaN): L is +inf / NaN and thr = inf - inf = NaN.  alpha = opacity * G <= 0 < 1/255 for every
+        // pixel, so the record can never contribute: say so explicitly (threshold +inf, empty box) instead of relying
+        // on how the three blend kernels' comparisons treat a NaN threshold
+        if (!(opac > 0.0f) || !(L < __builtin_huge_valf())) {
+          thr = __builtin_huge_valf(); ex = -__builtin_huge_valf(); ey = -__builtin_huge_valf();
+        }
         out.thr = thr; out.ex = ex; out.ey = ey;
       }
     }

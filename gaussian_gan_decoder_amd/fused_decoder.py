@@ -28,9 +28,30 @@ def _permute_blocks(w: torch.Tensor) -> torch.Tensor:
     return w[:, idx]
 
 
+_IN_FEATURES = (35, 38, 39, 43, 46)   # colour, opacity, rotation, scale, xyz: 32 plane channels + xyz + the earlier heads
+
+
+def _check_decoder(decoder) -> None:
+    """The kernels hard-code SequentialDecoderReverse's chain (colour -> opacity -> rotation -> scale -> xyz, each head fed
+    the earlier heads' outputs) and its scale activation -softplus(s + 5) - 2.5: anything else -- SequentialDecoder (xyz
+    first, -2), ParallelDecoder (no chaining), the positional-encoding option -- would pack without complaint (same head
+    names, first-layer widths inside 35..48) and then decode silently wrong attributes and gradients."""
+    if not isinstance(decoder, SequentialDecoderReverse):
+        raise TypeError(f"the fused decoder kernels implement SequentialDecoderReverse only (got {type(decoder).__name__}); "
+                        "use the PyTorch module for the other decoder types")
+    if getattr(decoder, "use_xyz_embedding", False):
+        raise ValueError("the fused decoder kernels do not implement use_xyz_embedding; use the PyTorch module")
+    got = tuple(getattr(decoder, n).backbone[0].in_features for n in
+                ("color_decoder", "opacity_decoder", "rotation_decoder", "scale_decoder", "xyz_decoder"))
+    if got != _IN_FEATURES:
+        raise ValueError(f"fused decoder: first-layer widths {got} are not SequentialDecoderReverse's {_IN_FEATURES} "
+                         "(32 plane channels, 3-D positions)")
+
+
 def pack_weights(decoder: SequentialDecoderReverse) -> torch.Tensor:
     """-> uint8 tensor of ggd_decoder_packed_bytes(): per head [W1 128x72 | W2 128x136 | W3 128x136 | W4 16x136] bf16,
     then b1 b2 b3 [128] and b4 [16] fp32."""
+    _check_decoder(decoder)
     dev = next(decoder.parameters()).device
     chunks = []
     for head in (decoder.color_decoder, decoder.opacity_decoder, decoder.rotation_decoder, decoder.scale_decoder,
@@ -66,6 +87,7 @@ ROW4T = 32 + 8
 
 def _head_tensors(decoder):
     """[(W1,b1,W2,b2,W3,b3,W4,b4)] * 5 in head order."""
+    _check_decoder(decoder)
     out = []
     for name in _HEADS:
         bb = getattr(decoder, name).backbone

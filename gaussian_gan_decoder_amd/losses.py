@@ -24,7 +24,7 @@ class _FusedImageLoss(torch.autograd.Function):
     def forward(ctx, image, target, weights):
         from . import _capi
         if not image.is_cuda:
-            raise RuntimeError("fused_image_loss is a HIP kernel: CUDA tensors required (use image_loss_torch on CPU)")
+            raise RuntimeError("fused_image_loss is a HIP kernel: HIP device tensors required (there is no CPU form in the package)")
         if image.dim() != 3 or image.shape[0] != 3 or image.shape != target.shape:
             raise ValueError("image and target must both be [3,H,W]")
         dev = image.device
@@ -53,7 +53,7 @@ class _FusedImageLoss(torch.autograd.Function):
 
 
 def fused_image_loss(image, target, l1_weight=0.2, l2_weight=0.1, ssim_weight=0.5, sobel_weight=0.2):
-    """(total, terms[5] = L1, L2, 1-SSIM, Sobel, total): same value and d/d(image) as `image_loss_torch`, three HIP
+    """(total, terms[5] = L1, L2, 1-SSIM, Sobel, total): same value and d/d(image) as the torch evaluation under tests/, three HIP
     launches instead of ~60 torch kernels.  `target` receives no gradient."""
     return _FusedImageLoss.apply(image, target, (l1_weight, l2_weight, ssim_weight, sobel_weight))
 

@@ -79,7 +79,7 @@ class DecoderTrainer:
                  l1_weight: float = 0.2, l2_weight: float = 0.1, ssim_weight: float = 0.5, sobel_weight: float = 0.2,
                  loss_fn=None, process_group=None, fused_activations: bool = False, fused_decoder: bool = False,
                  backbone_params: int = 0, perceptual_weight: float = 0.0, perceptual_width_div: int = 1,
-                 scene_streams: bool = False, fused_loss: bool = True):
+                 scene_streams: bool = False):
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.pg = process_group
@@ -192,12 +192,13 @@ class DecoderTrainer:
                     nbytes += (c1 - c0) * 4
                 works.append(ws)
         for k, (s, e, _) in enumerate(self.buckets):
+            g = self.flat_grad[s:e]
             if works:
                 for w in works[k]:
                     w.wait()
-                g = self.flat_grad[s:e]
                 g /= world
-                torch.nan_to_num(g, nan=0.0, posinf=1e5, neginf=-1e5, out=g)
+            # the reference sanitises on every step, single-GPU runs included (eg3d/training/training_loop.py:288-299)
+            torch.nan_to_num(g, nan=0.0, posinf=1e5, neginf=-1e5, out=g)
             self.optims[k].step()
         self.last_allreduce_bytes = nbytes
         return nbytes

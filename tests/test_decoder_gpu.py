@@ -62,7 +62,7 @@ def _bf16_reference(dec, feats, pos):
     return dict(color=color, opacity=opac, rotation=rot, scale=scale, xyz=xyz)
 
 
-@pytest.mark.parametrize("N", [1, 33, 5000, 100003])
+@pytest.mark.parametrize("N", [1, 33, 5000, 100003, 1_000_000])   # the last: BASELINE config 4's size
 def test_fused_decoder_matches_torch(native_lib, N):
     from gaussian_gan_decoder_amd.fused_decoder import FusedDecoder
     dev = torch.device("cuda:0")

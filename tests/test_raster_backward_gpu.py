@@ -150,9 +150,107 @@ def test_autograd_api_matches_oracle(native_lib):
     assert worst <= 1.0, report
 
 
+def test_fused_activation_prologue_matches_oracle(native_lib):
+    """SURVEY.md 8f row 2 (`raw_attributes` / render_simple(fused_activations=True): sigmoid / exp / normalize inside the
+    preprocess kernel, their Jacobians inside the preprocess-backward kernel) AGAINST THE ORACLE: the activations of
+    gaussian_model.py:100-121 are applied in numpy (float64, rounded once to fp32: exp, x / max(||x||, 1e-12), sigmoid),
+    the oracle renders that scene, `backward_ref64` gives the fp64 gradients w.r.t. the ACTIVATED attributes with their
+    per-element fp32 budgets, and both are chained through the activations' Jacobians in float64 exactly as
+    test_autograd_api_matches_oracle does for the torch getters.  Same per-element tolerance
+    |gpu - ref| <= 1e-5 + KAPPA * 2^-24 * budget, no outlier allowance.  The kernel's expf / sigmoid / normalize may differ
+    from the correctly rounded numpy values by an ulp, so the per-Gaussian forward state is compared with a tolerance
+    instead of bit-for-bit, and the integer stages (radii, lists) must still come out identical for this scene."""
+    import math
+    from gaussian_gan_decoder_amd.gaussian_model import GaussianModel
+    from gaussian_gan_decoder_amd.gaussian_renderer import render_simple
+    from gaussian_gan_decoder_amd.synthetic import make_scene
+    from gaussian_gan_decoder_amd import _capi
+    from _util import decode_buffers
+    from oracle import ggd_oracle as O
+    dev = torch.device("cuda:0")
+    S, P = 192, 20000
+    sc_cpu = make_scene(P, S, "shell", seed=9, log_scale_mean=-5.2)
+    rot_raw = (sc_cpu.rot_raw * 1.7).contiguous()                        # deliberately not unit length
+    sc = sc_cpu.to(dev)
+    pc = GaussianModel(0)
+    pc._xyz = sc.xyz.clone().requires_grad_(True)
+    pc._scaling = sc.log_scales.clone().requires_grad_(True)
+    pc._rotation = rot_raw.to(dev).clone().requires_grad_(True)
+    pc._opacity = sc.opacity_logit.clone().requires_grad_(True)
+    pc._features_dc = sc.features_dc.clone().requires_grad_(True)
+    # capture the buffers the fused forward saves: run the same call through the native wrapper as well
+    from gaussian_gan_decoder_amd import rasterizer as R
+    cam_d = sc.cam
+    out = render_simple(cam_d, pc, bg_color=sc.bg, fused_activations=True)
+    g = make_dL_dpix(S)
+    (out["render"] * g.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    cpu = lambda t: t.detach().cpu()
+    # numpy activations (float64, one rounding to fp32)
+    ls64, rr64, ol64 = (sc_cpu.log_scales.double().numpy(), rot_raw.double().numpy(), sc_cpu.opacity_logit.double().numpy())
+    scales = np.exp(ls64).astype(np.float32)
+    qn = np.maximum(np.linalg.norm(rr64, axis=1, keepdims=True), 1e-12)
+    rots = (rr64 / qn).astype(np.float32)
+    opac = (1.0 / (1.0 + np.exp(-ol64))).astype(np.float32)
+    cam = sc_cpu.cam
+    d = dict(P=P, W=S, H=S, sh_degree=0, scale_modifier=1.0, tanfovx=math.tan(cam.FoVx * 0.5),
+             tanfovy=math.tan(cam.FoVy * 0.5), means3D=sc_cpu.xyz, opacities=torch.from_numpy(opac),
+             viewmatrix=cam.world_view_transform.contiguous(), projmatrix=cam.full_proj_transform.contiguous(),
+             campos=cam.camera_center, bg=sc_cpu.bg, shs=sc_cpu.features_dc.contiguous(), colors_precomp=None,
+             scales=torch.from_numpy(scales), rotations=torch.from_numpy(rots), cov3D_precomp=None)
+    o = run_oracle(d)
+    # the fused forward once more through the native wrapper (deterministic) to look at what it saved
+    t = lambda x: x.to(dev)
+    nr, color, radii, geom, binning, img = R.rasterize_gaussians_native(
+        t(d["bg"]), t(d["means3D"]), torch.empty(0, device=dev), pc._opacity.detach(), pc._scaling.detach(),
+        pc._rotation.detach(), 1.0, torch.empty(0, device=dev), t(d["viewmatrix"]), t(d["projmatrix"]), d["tanfovx"],
+        d["tanfovy"], S, S, t(d["shs"]), 0, t(d["campos"]), False, False, True)
+    n = decode_buffers(P, S, S, nr, geom, binning, img)
+    assert torch.equal(color, out["render"])
+    # integer stages identical, float state within a few ulp of the oracle's
+    np.testing.assert_array_equal(cpu(out["radii"]).numpy(), o["radii"])
+    assert nr == o["num_rendered"]
+    np.testing.assert_array_equal(n["point_list"], o["point_list"])
+    np.testing.assert_array_equal(n["ranges"], o["ranges"])
+    vis = o["radii"] > 0
+    np.testing.assert_array_equal(n["xy"][vis], o["xy"][vis])                    # positions do not pass an activation
+    np.testing.assert_allclose(n["conic_opacity"][vis], o["conic_opacity"][vis], rtol=2e-4, atol=1e-6)
+    same = n["n_contrib"] == o["n_contrib"]
+    assert (~same).sum() <= 2, int((~same).sum())
+    err = np.abs(cpu(out["render"]).numpy() - o["color"])[:, same].max()
+    assert err <= 1e-5, err
+    ref, bud, fragile = O.backward_ref64(o, g.numpy(), final_T=n["final_T"], n_contrib=n["n_contrib"],
+                                         point_list=n["point_list"], ranges=n["ranges"])
+    # chain through exp / normalize / sigmoid in float64 (values by autograd, budgets by the absolute Jacobians + the
+    # roundings of the chain itself -- identical to test_autograd_api_matches_oracle)
+    ls = torch.from_numpy(ls64).requires_grad_(True); rr = torch.from_numpy(rr64).requires_grad_(True)
+    ol = torch.from_numpy(ol64).requires_grad_(True)
+    s64, q64, o64 = torch.exp(ls), torch.nn.functional.normalize(rr), torch.sigmoid(ol)
+    torch.autograd.backward([s64, q64, o64], [torch.from_numpy(ref["dL_dscales"]), torch.from_numpy(ref["dL_drots"]),
+                                              torch.from_numpy(ref["dL_dopacity"]).view(-1, 1)])
+    sv, qv, ov = s64.detach().numpy(), q64.detach().numpy(), o64.detach().numpy()
+    gq, bq = np.abs(ref["dL_drots"]), bud["dL_drots"]
+    aq = np.abs(qv)
+    ref2 = dict(dL_dmeans3D=ref["dL_dmeans3D"], dL_dsh=ref["dL_dsh"], dL_dmeans2D=ref["dL_dmeans2D"],
+                dL_dscales=ls.grad.numpy(), dL_drots=rr.grad.numpy(), dL_dopacity=ol.grad.numpy().reshape(-1))
+    bud2 = dict(dL_dmeans3D=bud["dL_dmeans3D"], dL_dsh=bud["dL_dsh"], dL_dmeans2D=bud["dL_dmeans2D"],
+                dL_dscales=bud["dL_dscales"] * sv + 3.0 * np.abs(ref2["dL_dscales"]),
+                dL_drots=(bq + aq * (aq * bq).sum(1, keepdims=True)) / qn
+                + 8.0 * (gq + aq * (aq * gq).sum(1, keepdims=True)) / qn,
+                dL_dopacity=(bud["dL_dopacity"] * (ov * (1 - ov)).reshape(-1) + 4.0 * np.abs(ref2["dL_dopacity"])))
+    got = dict(dL_dmeans3D=cpu(pc._xyz.grad).numpy(), dL_dsh=cpu(pc._features_dc.grad).numpy(),
+               dL_dmeans2D=cpu(out["viewspace_points"].grad).numpy(), dL_dscales=cpu(pc._scaling.grad).numpy(),
+               dL_drots=cpu(pc._rotation.grad).numpy(), dL_dopacity=cpu(pc._opacity.grad).numpy().reshape(-1))
+    report = []
+    worst = check_gradients(d, got, ref2, bud2, fragile, report=report)
+    print("\n" + "\n".join(f"  {r['array']:13s} max|err|={r['max_abs_err']:.3e} max|value|={r['max_abs_value']:.3e} "
+                            f"worst |err|/tol={r['worst_ratio']:.3f}" for r in report))
+    assert worst <= 1.0, report
+
+
 def test_fused_activation_prologue_matches_unfused(native_lib):
-    """render_simple(fused_activations=True) (sigmoid / exp / normalize inside the kernels) vs the
-    reference-shaped path (torch getters + autograd): same image, same gradients on the RAW attributes."""
+    """Secondary check of the same option (the oracle comparison is the test above): render_simple(fused_activations=True)
+    vs the reference-shaped path (torch getters + autograd) -- same image, same gradients on the RAW attributes."""
     from gaussian_gan_decoder_amd.gaussian_model import GaussianModel
     from gaussian_gan_decoder_amd.gaussian_renderer import render_simple
     from gaussian_gan_decoder_amd.synthetic import make_scene

@@ -105,6 +105,46 @@ def test_empty_and_all_culled(native_lib):
     np.testing.assert_array_equal(n["color"].cpu().numpy(), o["color"])
 
 
+def test_zero_negative_and_nan_opacity_never_contribute(native_lib):
+    """opacity exactly 0 and negative: ln(1 / (255 opacity)) is +inf / NaN there.  alpha = min(0.99, opacity * G) is
+    <= 0 < 1/255, so such a record can never contribute; the library says so explicitly (threshold +inf, empty box) instead
+    of relying on NaN comparison semantics: image, n_contrib and every gradient against the oracle, on all blend forms."""
+    from _util import run_native_backward, backward_reference, check_gradients
+    from gaussian_gan_decoder_amd.synthetic import make_dL_dpix
+    from gaussian_gan_decoder_amd import _capi
+    d = scene_inputs(P=3000, size=96, lsm=-4.0, seed=31)
+    op = d["opacities"].clone()
+    op[0:300] = 0.0
+    op[300:600] = -0.25
+    op[600:700] = -1e-30
+    op[700:800] = 1e-30                    # positive but far below 1/255: the ordinary path
+    d["opacities"] = op.contiguous()
+    o = run_oracle(d)
+    g = make_dL_dpix(96)
+    cx = _capi.context_for(torch.device("cuda:0"))
+    saved = cx.get_option(_capi.OPT_BLEND_SPLIT)
+    try:
+        for split in (1, 0, 2):
+            cx.set_option(_capi.OPT_BLEND_SPLIT, split)
+            n = run_native(d, debug=False)
+            np.testing.assert_array_equal(n["radii"].cpu().numpy(), o["radii"])
+            np.testing.assert_array_equal(n["point_list"], o["point_list"])
+            thr = n["power_threshold"]
+            vis = o["radii"] > 0
+            dead = vis & (op.numpy().reshape(-1) <= 0)
+            assert dead.sum() > 100 and np.isposinf(thr[dead]).all() and np.isneginf(n["cull_extent"][dead]).all()
+            assert np.isfinite(thr[vis & ~dead]).all()
+            np.testing.assert_array_equal(n["n_contrib"], o["n_contrib"])
+            assert np.abs(n["color"].cpu().numpy() - o["color"]).max() <= RGB_ATOL
+            ref, budget, fragile = backward_reference(d, o, n, g.numpy())
+            nb = run_native_backward(d, n, g)
+            assert check_gradients(d, nb, ref, budget, fragile) <= 1.0
+            for name in ("dL_dopacity", "dL_dcolors", "dL_dmeans2D"):
+                assert (nb[name].reshape(d["P"], -1)[:700] == 0).all(), name     # nothing ever reaches a dead record
+    finally:
+        cx.set_option(_capi.OPT_BLEND_SPLIT, saved)
+
+
 @pytest.mark.parametrize("path", [2, 3], ids=["tilebin", "rowbin"])
 def test_single_call_forward_capacity_overflow_is_retried(native_lib, path):
     """The torch wrapper sizes the binning buffer of the single-call (speculative) forward from the previous frame of
