@@ -206,6 +206,44 @@ void ggo_render_backward_ref64(const ggo_params* prm, const float* bg, const uin
     }
 }
 
+/* Pixels whose fp32 blend contains a DECISION that one ulp of exp() can flip: a (pixel, Gaussian) pair whose alpha sits
+ * within `window` (relative) of the 1/255 floor, or a transmittance test T (1 - alpha) within 4 `window` of the 1e-4 stop.
+ * Walks every pixel front to back exactly as the fp32 forward (ggo_render_f32).  A flip in the middle of a pixel's list
+ * changes the transmittance of everything behind it by a factor (1 - 1/255): both outcomes are correct fp32 results, but
+ * they differ by far more than rounding, in the pixel's colour and in the gradient of every Gaussian behind the flipped
+ * one.  The parity tests therefore compare colours on the other pixels and give these pixels zero upstream gradient (for
+ * the HIP backward and for the reference alike), and bound their number. */
+int64_t ggo_fragile_pixels(const ggo_params* prm, const uint32_t* ranges, const uint32_t* list, const float* xy,
+                           const float* conic_opacity, double window, uint8_t* mask /*[H*W]*/) {
+  const int W = prm->W, H = prm->H, gx = (W + 15) / 16;
+  const float alpha_floor = 1.0f / 255.0f;
+  int64_t count = 0;
+  for (int py = 0; py < H; ++py)
+    for (int px = 0; px < W; ++px) {
+      const int tile = (py / 16) * gx + (px / 16);
+      const uint32_t lo = ranges[2 * tile], hi = ranges[2 * tile + 1];
+      float T = 1.0f;
+      uint8_t frag = 0;
+      for (uint32_t j = lo; j < hi; ++j) {
+        const uint32_t id = list[j];
+        const float dx = xy[2 * id] - (float)px, dy = xy[2 * id + 1] - (float)py;
+        const float* co = conic_opacity + 4 * id;
+        const float power = gauss_power_f32(co[0], co[1], co[2], dx, dy);
+        if (power > 0.0f) continue;
+        const float alpha = rmin_f32(0.99f, co[3] * expf(power));
+        if (fabs((double)alpha * 255.0 - 1.0) <= window) frag = 1;
+        if (alpha < alpha_floor) continue;
+        const float test_T = T * (1.0f - alpha);
+        if (fabs((double)test_T * 1e4 - 1.0) <= 4.0 * window) frag = 1;   /* T carries the exp() ulps of every contributor in front */
+        if (test_T < 0.0001f) break;
+        T = test_T;
+      }
+      mask[(size_t)py * W + px] = frag;
+      count += frag;
+    }
+  return count;
+}
+
 /* ---- unit-test entry points (let tests/golden pin the pieces that DO have an in-tree Python twin) ----------- */
 void ggo_test_sh_to_rgb(int deg, const float* sh /*[M][3]*/, const float* p, const float* campos, float* rgb,
                         uint8_t* clamped) {

@@ -43,6 +43,7 @@ def lib():
         build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.ggo_scan.restype = C.c_int64
+        _lib.ggo_fragile_pixels.restype = C.c_int64
         _lib.ggo_higher_msb.restype = C.c_uint32
     return _lib
 
@@ -234,6 +235,20 @@ def backward_ref64(fwd: dict, dL_dpix, final_T=None, n_contrib=None, point_list=
     ref.update(dL_dmeans2D=d_means2D, dL_dconic=co, dL_dopacity=dop * vis, dL_dcolors=dc * vis[:, None])
     budget.update(dL_dmeans2D=b_means2D, dL_dconic=Sco, dL_dopacity=Sop * vis, dL_dcolors=Sdc * vis[:, None])
     return ref, budget, fragile
+
+
+def fragile_pixels(fwd: dict, window: float = 1e-6, point_list=None, ranges=None):
+    """bool[H, W]: pixels whose fp32 blend holds a decision within `window` of a threshold (alpha floor 1/255, transmittance
+    stop 1e-4) -- see ggo_fragile_pixels in ggd_oracle.c.  `fwd` is an fp32 forward() dict."""
+    L = lib()
+    assert fwd["dtype"] == np.float32
+    W, H = fwd["W"], fwd["H"]
+    pl = _c(fwd["point_list"] if point_list is None else point_list, np.uint32)
+    rg = _c(fwd["ranges"] if ranges is None else ranges, np.uint32, (-1, 2))
+    mask = np.zeros((H, W), np.uint8)
+    L.ggo_fragile_pixels(C.byref(fwd["prm"]), _p(rg), _p(pl), _p(fwd["xy"]), _p(fwd["conic_opacity"]),
+                         C.c_double(window), _p(mask))
+    return mask.astype(bool)
 
 
 def mark_visible(means3D, viewmatrix):

@@ -147,6 +147,18 @@ def run_native_backward(d, n, dL_dpix, device="cuda:0"):
     return {k: v.cpu().numpy() for k, v in zip(names, outs)}
 
 
+def fragile_pixels(o, per=20000):
+    """bool[H, W] of the pixels whose fp32 blend holds a decision one ulp of exp() can flip (oracle/ggd_oracle.c::
+    ggo_fragile_pixels: an alpha within 1e-6 of the 1/255 floor or a transmittance test within 1e-6 of the 1e-4 stop).  Both
+    outcomes are correct fp32 results but differ by ~1/255 of everything behind the flipped contributor, so the parity tests
+    compare colours on the other pixels and zero the upstream gradient of these (for the HIP backward and the reference
+    alike).  Their number is bounded: at most one per `per` pixels (+2)."""
+    from oracle import ggd_oracle as O
+    m = O.fragile_pixels(o)
+    assert int(m.sum()) <= 2 + (o["W"] * o["H"]) // per, f"{int(m.sum())} fragile pixels"
+    return m
+
+
 EPS32 = 2.0 ** -24
 ATOL = 1e-5      # the north_star's absolute bar
 KAPPA = 0.25     # factor on the (worst-case) fp32 error budget of the reference (oracle/ggd_oracle.py::backward_ref64):

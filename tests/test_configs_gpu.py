@@ -14,7 +14,8 @@ import numpy as np
 import pytest
 import torch
 
-from _util import (scene_inputs, run_oracle, run_native, run_native_backward, backward_reference, check_gradients)
+from _util import (scene_inputs, run_oracle, run_native, run_native_backward, backward_reference, check_gradients,
+                   fragile_pixels)
 from gaussian_gan_decoder_amd.synthetic import make_dL_dpix
 
 pytestmark = pytest.mark.gpu
@@ -31,7 +32,13 @@ def test_large_tile_grids_match_oracle(native_lib, W, H, modes):
     lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
     print(f"\n  {W}x{H}: tiles {o['T']}, R = {R}, visible {int(vis.sum())}, tile list length mean {lens.mean():.0f} max {lens.max()}")
     assert R > 1_000_000                  # past the auto rule's switch to tile binning where the grid allows it
+    # pixels holding a threshold decision that an ulp of exp() flips (with splats this large -- sigma ~ 10 px, several
+    # hundred contributors per pixel -- there are a few per frame): excluded from the colour comparison, zero upstream
+    # gradient in the backward comparison
+    frag = fragile_pixels(o)
+    print(f"  fragile pixels: {int(frag.sum())}")
     g = make_dL_dpix(max(W, H))[:, :H, :W].contiguous()
+    g[:, torch.from_numpy(frag)] = 0.0
     base = None
     for mode in modes:
         for rep in range(2):              # second call of a shape: the single-call (capacity-hint) form where it exists
@@ -47,7 +54,8 @@ def test_large_tile_grids_match_oracle(native_lib, W, H, modes):
             color = n["color"].cpu().numpy()
             same = n["n_contrib"] == o["n_contrib"]
             assert int((~same).sum()) <= max(2, (W * H) // 100000)
-            err = np.abs(color - o["color"])[:, same].max()
+            assert (same | frag).all(), "an n_contrib mismatch outside the fragile pixels"
+            err = np.abs(color - o["color"])[:, same & ~frag].max()
             assert err <= 1e-5, f"binning={mode}: max |dRGB| = {err}"
             if base is None:
                 base = color
