@@ -147,7 +147,7 @@ def run_native_backward(d, n, dL_dpix, device="cuda:0"):
     return {k: v.cpu().numpy() for k, v in zip(names, outs)}
 
 
-def fragile_pixels(o, per=20000):
+def fragile_pixels(o, per=5000):
     """bool[H, W] of the pixels whose fp32 blend holds a decision one ulp of exp() can flip (oracle/ggd_oracle.c::
     ggo_fragile_pixels: an alpha within 1e-6 of the 1/255 floor or a transmittance test within 1e-6 of the 1e-4 stop).  Both
     outcomes are correct fp32 results but differ by ~1/255 of everything behind the flipped contributor, so the parity tests
