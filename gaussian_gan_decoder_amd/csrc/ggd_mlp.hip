@@ -299,10 +299,26 @@ __global__ __launch_bounds__(FWD_THREADS, FWD_WAVES / 4) void decoder_forward_ke
 
 #include "ggd_mlp_bwd.inc"
 #include "ggd_mlp_wgrad.inc"
+#include "ggd_mlp_pack.inc"
 
 }  // namespace
 
 extern "C" size_t ggd_decoder_packed_bytes(void) { return (size_t)NHEAD * HEAD_BYTES; }
+
+extern "C" int ggd_decoder_pack(ggd_ctx* ctx, void* stream, const float* const* params40, void* packed, void* packed_t) {
+  if (!ctx) return GGD_E_INVALID;
+  if (!params40 || !packed) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_pack: NULL pointer");
+  ggd_pack_ptrs ptrs;
+  for (int i = 0; i < NHEAD * 8; ++i) {
+    if (!params40[i]) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_pack: NULL parameter pointer");
+    ptrs.p[i] = params40[i];
+  }
+  const int total = NHEAD * PACK_PER_HEAD;
+  hipLaunchKernelGGL(decoder_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), ptrs,
+                     static_cast<unsigned char*>(packed), static_cast<unsigned char*>(packed_t));
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
 
 static int decoder_forward_impl(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
                                 const void* packed_weights, float* attrs, void* zbuf) {

@@ -129,6 +129,28 @@ def _splitk_dw(dy: torch.Tensor, x: torch.Tensor, chunk: int = 4096) -> torch.Te
     return dw
 
 
+def device_pack(decoder, params=None, buffers=None):
+    """(packed, packed_t) built by the library's pack kernel from the decoder's 40 parameter tensors (head order colour,
+    opacity, rotation, scale, xyz; W1 b1 .. W4 b4).  Same bytes as pack_weights / pack_weights_t, which stay the host-side
+    statement of the format.  `buffers`: a previous result to overwrite in place."""
+    if params is None:
+        params = [t for head in _head_tensors(decoder) for t in head]
+    dev = params[0].device
+    if dev.type != "cuda":
+        raise RuntimeError("the fused decoder is a HIP kernel: CUDA tensors required (use the PyTorch decoder on CPU)")
+    ps = [p.detach() for p in params]
+    ps = [p if (p.dtype == torch.float32 and p.is_contiguous()) else p.float().contiguous() for p in ps]
+    cx = _capi.context_for(dev)
+    if buffers is None or buffers[0].device != dev:
+        buffers = (torch.empty((cx.lib.ggd_decoder_packed_bytes(),), dtype=torch.uint8, device=dev),
+                   torch.empty((cx.lib.ggd_decoder_packed_t_bytes(),), dtype=torch.uint8, device=dev))
+    table = (C.c_void_p * 40)(*[p.data_ptr() for p in ps])
+    with torch.cuda.device(dev):
+        cx.check(cx.lib.ggd_decoder_pack(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), table,
+                                         C.c_void_p(buffers[0].data_ptr()), C.c_void_p(buffers[1].data_ptr())))
+    return buffers
+
+
 import os as _os
 
 # points per backward / weight-gradient chunk (z + dz of a chunk = 15 KiB per point; 0 = no chunking)
@@ -234,19 +256,19 @@ class FusedTrainDecoder(torch.nn.Module):
     def __init__(self, decoder: SequentialDecoderReverse):
         super().__init__()
         self.decoder = decoder
-        self._packed_key = None
-        self._packed = None
+        _check_decoder(decoder)
+        self._buffers = None
 
     def get_params_custom(self):
         return self.decoder.get_params_custom()
 
     def _images(self, params):
-        """Weight images, rebuilt only when a parameter changed (optimizer steps bump Tensor._version)."""
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        if key != self._packed_key:
-            self._packed = (pack_weights(self.decoder), pack_weights_t(self.decoder))
-            self._packed_key = key
-        return self._packed
+        """Weight images for this call: ONE device launch (ggd_decoder_pack) straight from the parameter tensors, on every
+        forward.  (They used to be cached on the parameters' `_version`; torch's fused Adam updates parameters without
+        bumping it, so a trainer kept decoding with the images of step 0.)"""
+        packed, packed_t = device_pack(self.decoder, params, self._buffers)
+        self._buffers = (packed, packed_t)
+        return packed, packed_t
 
     def forward_scenes(self, planes_list, positions):
         """Several scenes (own feature planes, positions[B,N,3]) through ONE decoder launch: attrs[B,N,16].  The
@@ -276,7 +298,11 @@ class FusedDecoder:
         self.repack()
 
     def repack(self):
-        self.packed = pack_weights(self.decoder)
+        """Rebuild the weight image after the wrapped decoder's parameters changed."""
+        if next(self.decoder.parameters()).is_cuda:
+            self.packed = device_pack(self.decoder)[0]
+        else:
+            self.packed = pack_weights(self.decoder)
 
     @torch.no_grad()
     def decode_features(self, feats: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:

@@ -265,6 +265,11 @@ int ggd_surface_sample(ggd_ctx* ctx, void* stream, const float* sigma, int32_t n
  *                      [11..13] xyz (= head*0.01 + pos), [14..15] zero
  */
 size_t ggd_decoder_packed_bytes(void);
+/* Build the weight images on the device in ONE launch: params40 = HOST array of 40 DEVICE pointers, per head (colour,
+ * opacity, rotation, scale, xyz) W1 b1 W2 b2 W3 b3 W4 b4 as torch.nn.Linear stores them (fp32, [out][in] row-major;
+ * in = 35, 38, 39, 43, 46, out = 3, 1, 4, 3, 3); packed: ggd_decoder_packed_bytes(), packed_t (may be NULL):
+ * ggd_decoder_packed_t_bytes().  Training calls it after every optimizer step. */
+int ggd_decoder_pack(ggd_ctx* ctx, void* stream, const float* const* params40, void* packed, void* packed_t);
 int ggd_decoder_forward(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
                         const void* packed_weights, float* attrs);
 

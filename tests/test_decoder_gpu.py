@@ -145,3 +145,41 @@ def test_fused_decoder_matches_reference_class_fixture(native_lib):
         np.testing.assert_allclose(getattr(o32, k).cpu().numpy(), ref, atol=2e-5, rtol=1e-5, err_msg=k)
         scale = max(1.0, float(np.abs(ref).max()))
         assert float(np.abs(getattr(o16, k).cpu().numpy() - ref).max()) <= 5e-2 * scale, k
+
+
+def test_device_pack_matches_the_host_statement_of_the_format(native_lib):
+    """ggd_decoder_pack (one launch, what training runs after every optimizer step) == fused_decoder.pack_weights /
+    pack_weights_t (torch ops: the host-side statement of the two image formats), byte for byte."""
+    from gaussian_gan_decoder_amd.fused_decoder import pack_weights, pack_weights_t, device_pack
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    dec = SequentialDecoderReverse().to(dev)
+    for p in dec.parameters():
+        p.data = torch.randn_like(p) * 0.7
+    packed, packed_t = device_pack(dec)
+    assert torch.equal(packed, pack_weights(dec))
+    assert torch.equal(packed_t, pack_weights_t(dec))
+
+
+def test_fused_train_decoder_follows_an_optimizer_step(native_lib):
+    """torch's fused Adam updates parameters without bumping Tensor._version; the fused decoder must still decode with
+    the new weights (it used to cache its weight images on the version counters and train a frozen decoder)."""
+    from gaussian_gan_decoder_amd.fused_decoder import FusedTrainDecoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    mod = SequentialDecoderReverse().to(dev)
+    fused = FusedTrainDecoder(mod)
+    planes = torch.randn(3, 32, 32, 32, device=dev)
+    pos = torch.rand(4096, 3, device=dev) - 0.5
+    opt = torch.optim.Adam(mod.parameters(), lr=1e-2, fused=True)
+    outs = []
+    for _ in range(3):
+        o = fused(planes, pos)
+        outs.append(o.color.detach().clone())
+        (o.color.square().mean() + o.scale.mean()).backward()
+        opt.step(); opt.zero_grad()
+    with torch.no_grad():
+        ref = mod(planes, pos).color
+        now = fused(planes, pos).color
+    assert (outs[1] - outs[0]).abs().max().item() > 1e-3 and (outs[2] - outs[1]).abs().max().item() > 1e-3
+    assert (now - ref).abs().max().item() <= 5e-2 * max(1.0, ref.abs().max().item())
