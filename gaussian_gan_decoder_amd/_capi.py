@@ -11,7 +11,8 @@ import os
 import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libggd_raster.so")
+# GGD_LIB_PATH: load another build of the library (A/B timing of kernel variants inside one process launch)
+LIB_PATH = os.environ.get("GGD_LIB_PATH") or os.path.join(_PKG, "libggd_raster.so")
 
 EXPORTS = [
     "ggd_geom_bytes", "ggd_binning_bytes", "ggd_img_bytes", "ggd_geom_layout", "ggd_binning_layout",

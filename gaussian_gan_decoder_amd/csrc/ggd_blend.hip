@@ -216,32 +216,49 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
   const float wy0 = (float)(g.py - lane / Geom::LPR), wy1 = wy0 + (float)(Geom::BH - 1);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-  // staged record (three 16-byte LDS words, read back as broadcasts), shuffled from the 48-byte ggd_splat so that the
-  // cull stage needs the first two words only:
-  //   q0 = {x, y, -A/2, -B}   q1 = {-C/2, power threshold, opacity, contributor index (1-based list position)}
-  //   q2 = {r, g, b, -}
-  float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
+  // staged record = the 48-byte ggd_splat as loaded, two words replaced in place (three 16-byte LDS words, read back as
+  // broadcasts; the cull stage needs the first two only):
+  //   q0 = {x, y, -A/2, -B}   q1 = {-C/2, power threshold, opacity, r}   q2 = {g, b, contributor index (1-based list
+  //   position; replaces the cull extent ex), -}
+  // No component moves between the three words: forming a new 4-register tuple from parts of two loaded ones made the
+  // register allocator copy those parts right behind the loads, i.e. wait for them there.
   bool keep = false;
-  auto fetch = [&](uint32_t pos) {
+  // The gather is a two-stage software pipeline, each stage one round (64 list entries) ahead of its consumer: the list
+  // entries of round k + 2 and the 48-byte records of round k + 1 are in flight while round k is blended, and nothing is
+  // waited for until the values are needed at the top of the next round.  (With the cull arithmetic inside the fetch the
+  // compiler had to wait for both dependent loads -- list entry, then record -- right where they were issued: two exposed
+  // memory round trips per round.)
+  uint32_t id_nxt = 0;
+  float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;   // x y hA nB | hC thr opacity r | g b ex ey
+  // (unconditional loads from clamped positions: a lane past the end of the list re-reads the last entry -- one cache
+  // line for the whole wave -- and its record is never consumed; exec-masked loads made r0..r2 loop-carried merges that the
+  // register allocator split with copies right behind the loads, i.e. waits)
+  const uint32_t last_pos = g.hi - 1u;   // only used when g.hi > g.lo
+  auto load_id = [&](uint32_t pos) { id_nxt = list[min(pos, last_pos)]; };
+  auto load_rec = [&](uint32_t) {
+    const float4* p = reinterpret_cast<const float4*>(splat + id_nxt);
+    r0 = p[0]; r1 = p[1]; r2 = p[2];
+  };
+  auto consume = [&](uint32_t pos) {   // cull decision of the record in r0..r2, then its two in-place edits
     keep = false;
     if (pos < g.hi) {
-      const float4* p = reinterpret_cast<const float4*>(splat + list[pos]);
-      const float4 r0 = p[0], r1 = p[1], r2 = p[2];   // x y hA nB | hC thr opacity r | g b ex ey
-      q0 = r0;
-      q1 = make_float4(r1.x, CULL ? r1.y : -__builtin_huge_valf(), r1.z, __uint_as_float(pos - g.lo + 1u));
-      q2 = make_float4(r1.w, r2.x, r2.y, 0.0f);
       keep = CULL ? (record_box_hits(r0.x, r0.y, r2.z, r2.w, wx0, wx1, wy0, wy1) &&
                      record_reaches_block(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, wx0, wx1, wy0, wy1)) : true;
+      if (!CULL) r1.y = -__builtin_huge_valf();
+      r2.z = __uint_as_float(pos - g.lo + 1u);
     }
   };
-  fetch(g.lo + lane);
-  if (!wave_alive()) goto all_done;
+  if (g.hi <= g.lo || !wave_alive()) goto all_done;
+  load_id(g.lo + lane);
+  load_rec(g.lo + lane);
+  load_id(g.lo + 64 + lane);
   for (uint32_t base = g.lo; base < g.hi; base += 64) {
+    consume(base + lane);          // the records requested one round ago
     __syncthreads();  // single-wave block: orders the previous round's LDS reads before this round's writes
     const uint64_t kept = __ballot(keep);
     if (keep) {  // compacted: only records whose box reaches this wave's pixels are staged
       const int slot = __popcll(kept & lt_mask);
-      s_rec[slot * 3 + 0] = q0; s_rec[slot * 3 + 1] = q1; s_rec[slot * 3 + 2] = q2;
+      s_rec[slot * 3 + 0] = r0; s_rec[slot * 3 + 1] = r1; s_rec[slot * 3 + 2] = r2;
     }
     // the staged list is padded to a multiple of 8 with records no pixel can see (threshold +inf), so that a group of 8
     // is straight-line code: LDS addresses are immediates, there is no loop counter, and a record that no pixel of the
@@ -256,7 +273,8 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
       st_visited += min(64u, g.hi - base);
       st_culled += min(64u, g.hi - base) - (uint32_t)__popcll(kept);
     }
-    fetch(base + 64 + lane);  // next round's gather is in flight while this round is blended
+    load_rec(base + 64 + lane);    // next round's records (their list entries were requested one round ago)
+    load_id(base + 128 + lane);    // and the list entries of the round after it
     __syncthreads();
     for (int j0 = 0; j0 < n8; j0 += 8) {
       if (!wave_alive()) goto all_done;
@@ -283,9 +301,9 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
           for (int k = 0; k < PXL; ++k) { lanes |= need[k]; st_pixels += (uint32_t)__popcll(need[k]); }
           st_lanes += (uint32_t)__popcll(lanes);
         }
-        const float2 b23 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(grp + jj * 3 + 1) + 2);
-        const float4 c = grp[jj * 3 + 2];
-        const uint32_t contributor = __float_as_uint(b23.y);
+        const float2 b23 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(grp + jj * 3 + 1) + 2);   // opacity, r
+        const float4 c = grp[jj * 3 + 2];                                                                             // g, b, contributor
+        const uint32_t contributor = __float_as_uint(c.z);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
           const float G = blend_exp<EXP_MODE>(pw[k]);
@@ -295,9 +313,9 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
           const uint64_t low = __ballot(test_T < 0.0001f);
           const uint64_t upd = live & ~low, stop = live & low;
           const float w = sel_or_zero(alpha * Tr[k], upd);
-          fma_into(C[k][0], c.x, w);
-          fma_into(C[k][1], c.y, w);
-          fma_into(C[k][2], c.z, w);
+          fma_into(C[k][0], b23.y, w);
+          fma_into(C[k][1], c.x, w);
+          fma_into(C[k][2], c.y, w);
           sel_into_after(Tr[k], test_T, upd, w);
           sel_into(last[k], contributor, upd);
           sel_into(px[k], INF, stop);
@@ -676,44 +694,59 @@ __global__ __launch_bounds__(256 / PXL) void blend_backward_tile_kernel(
                         : (writer_val < 6 ? GGD_ACC_CONIC + (writer_val - 3)
                         : (writer_val < 8 ? GGD_ACC_MEAN2D + (writer_val - 6) : GGD_ACC_OPACITY));
 
-  // staged: {x, y, hA, nB} {hC, power threshold, opacity, 0-based list position} {r, g, b, index inside the round}
-  float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
+  // staged = the record as loaded with three words replaced in place (no component changes its 16-byte word, see the forward):
+  //   {x, y, hA, nB} {hC, power threshold, opacity, 0-based list position} {g, b, r, index inside the round}
   bool keep = false;
-  uint32_t my_id = 0;
-  auto gather = [&](uint32_t ce) {   // the round that ends at list position ce (exclusive)
+  // Two-stage software pipeline of the gather, as in the forward: while round k is blended the records of round k + 1
+  // (the round in FRONT of it: the list is walked back to front) and the list entries of round k + 2 are in flight.
+  uint32_t id_cur = 0, id_nxt = 0;     // Gaussian ids of the round whose records are in r0..r2 / of the round after it
+  float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;    // x y hA nB | hC thr opacity r | g b ex ey
+  auto round_start = [&](uint32_t ce) { return (ce - rg.x > 64u) ? ce - 64u : rg.x; };   // ce > rg.x
+  // (unconditional loads from clamped positions, see the forward; maxn > 0 here, so the list is not empty)
+  auto load_id = [&](uint32_t ce) {    // the round that ends at list position ce (exclusive); ce <= rg.x: a dummy re-read
+    const uint32_t cs = ce > rg.x ? round_start(ce) : rg.x;
+    id_nxt = list[min(cs + (uint32_t)lane, rg.x + maxn - 1u)];
+  };
+  auto load_rec = [&](uint32_t) {
+    id_cur = id_nxt;
+    const float4* p = reinterpret_cast<const float4*>(splat + id_nxt);
+    r0 = p[0]; r1 = p[1]; r2 = p[2];
+  };
+  auto consume = [&](uint32_t ce) {
     keep = false;
-    if (ce <= rg.x) return;
-    const uint32_t cs = (ce - rg.x > 64u) ? ce - 64u : rg.x;
+    const uint32_t cs = round_start(ce);
     if ((uint32_t)lane < ce - cs) {
-      my_id = list[cs + lane];
-      const float4* p = reinterpret_cast<const float4*>(splat + my_id);
-      const float4 r0 = p[0], r1 = p[1], r2 = p[2];   // x y hA nB | hC thr opacity r | g b ex ey
-      q0 = r0;
-      q1 = make_float4(r1.x, CULL ? r1.y : -__builtin_huge_valf(), r1.z, __uint_as_float((cs - rg.x) + (uint32_t)lane));
-      q2 = make_float4(r1.w, r2.x, r2.y, __uint_as_float((uint32_t)lane));
       keep = CULL ? (record_box_hits(r0.x, r0.y, r2.z, r2.w, wx0, wx1, wy0, wy1) &&
                      record_reaches_block(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, wx0, wx1, wy0, wy1)) : true;
+      if (!CULL) r1.y = -__builtin_huge_valf();
+      r2.z = r1.w;                                                   // r joins g, b
+      r1.w = __uint_as_float((cs - rg.x) + (uint32_t)lane);          // 0-based list position
+      r2.w = __uint_as_float((uint32_t)lane);                        // index inside the round
     }
   };
 
   uint32_t cend = rg.x + maxn;  // one past the last position that matters
-  gather(cend);
+  load_id(cend);
+  load_rec(cend);
+  load_id(round_start(cend));
   int par = 0;
   while (cend > rg.x) {
-    const uint32_t cstart = (cend - rg.x > 64u) ? cend - 64u : rg.x;
+    const uint32_t cstart = round_start(cend);
     const int n = (int)(cend - cstart);
+    consume(cend);                                       // the records requested one round ago
     const uint64_t kept = __ballot(keep);
     const int nk = __popcll(kept), n8 = (nk + 7) & ~7;
     if (keep) {  // compacted, order preserved
       const int slot = __popcll(kept & lt_mask);
-      rec[slot * 3 + 0] = q0; rec[slot * 3 + 1] = q1; rec[slot * 3 + 2] = q2;
+      rec[slot * 3 + 0] = r0; rec[slot * 3 + 1] = r1; rec[slot * 3 + 2] = r2;
     }
     if (lane >= nk && lane < n8) {   // padding: a record nobody sees
       rec[lane * 3 + 0] = make_float4(0, 0, 0, 0);
       rec[lane * 3 + 1] = make_float4(0, __builtin_huge_valf(), 0, 0);
     }
-    if (wv == 0 && lane < n) { s_id[par][lane] = my_id; s_op[par][lane] = q1.z; }
-    gather(cstart);             // next round's records are in flight while this round is blended
+    if (wv == 0 && lane < n) { s_id[par][lane] = id_cur; s_op[par][lane] = r1.z; }
+    load_rec(cstart);                                    // next round's records
+    load_id(cstart > rg.x ? round_start(cstart) : rg.x); // and the list entries of the round after it
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     uint64_t touched = 0ull;
@@ -735,9 +768,9 @@ __global__ __launch_bounds__(256 / PXL) void blend_backward_tile_kernel(
           any |= need[k];
         }
         if (any == 0ull) continue;
-        const float4 c = grp[jj * 3 + 2];
+        const float4 c = grp[jj * 3 + 2];                            // g, b, r, index inside the round
         const float cA = -2.0f * a.z, cB = -a.w, cC = -2.0f * b.x;   // the conic (exact rescalings of hA, nB, hC)
-        const float col[3] = {c.x, c.y, c.z};
+        const float col[3] = {c.z, c.x, c.y};
         float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sop = 0.0f;   // colour r g b | conic A B C | mean x y ; opacity
         uint64_t any_live = 0ull;
 #pragma unroll

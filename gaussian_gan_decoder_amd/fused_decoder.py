@@ -257,7 +257,7 @@ class FusedTrainDecoder(torch.nn.Module):
         super().__init__()
         self.decoder = decoder
         _check_decoder(decoder)
-        self._buffers = None
+        self._image_bufs = None
 
     def get_params_custom(self):
         return self.decoder.get_params_custom()
@@ -266,8 +266,8 @@ class FusedTrainDecoder(torch.nn.Module):
         """Weight images for this call: ONE device launch (ggd_decoder_pack) straight from the parameter tensors, on every
         forward.  (They used to be cached on the parameters' `_version`; torch's fused Adam updates parameters without
         bumping it, so a trainer kept decoding with the images of step 0.)"""
-        packed, packed_t = device_pack(self.decoder, params, self._buffers)
-        self._buffers = (packed, packed_t)
+        packed, packed_t = device_pack(self.decoder, params, self._image_bufs)
+        self._image_bufs = (packed, packed_t)
         return packed, packed_t
 
     def forward_scenes(self, planes_list, positions):
