@@ -851,6 +851,197 @@ __global__ __launch_bounds__(256 / PXL) void blend_backward_tile_kernel(
   }
 }
 
+
+// ---- backward blend, quarter form: every 8x8 quarter of a tile is an INDEPENDENT single-wave workgroup --------------------
+// No workgroup barrier and no cross-wave combine: a wave walks the tile's list back to front from ITS OWN last contributor,
+// parks the per-record sums of a round in LDS in processing order (row = 9 sums + the Gaussian's id + its opacity), and
+// flushes them itself -- (record, component) pairs over the lanes, component fastest, so a record's nine atomics form one
+// 36-byte span -- at the top of the NEXT round, before that round's prefetch loads are issued: a wait for the loads then
+// never waits for younger atomics (loads and atomics share one in-order counter).  Compared with the tile form a Gaussian
+// that touches k quarters of a tile costs k coalesced atomic spans instead of one; in exchange the four quarters never wait
+// for each other (the tile form spent 13 % / 28 % of its time in the per-round lock step: cube / shell), and the four
+// quarters of a tile are placed in consecutive dispatch slots of one XCD like the forward's.
+template <int EXP_MODE, bool CULL>
+__global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
+    int W, int H, int gx, int gy, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ list,
+    const uint32_t* __restrict__ ranges, const float* __restrict__ bg, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
+  __shared__ float4 s_rec[64 * 3];
+  // [touched record, in processing order][9 sums | id | opacity | -]; ONE buffer: a round's rows are flushed at the top of the
+  // next round, before that round's first row is written (LDS operations of a wave execute in order)
+  __shared__ float s_sum[64][12];
+  const int lane = threadIdx.x;
+  int tile, sub;
+  ggd_block_to_tile((int)blockIdx.x, 4, gx, gy, gx * gy, tile, sub);
+  const int tx = tile % gx, ty = tile / gx;
+  const int qx = sub & 1, qy = sub >> 1;
+  const int px0 = tx * 16 + qx * 8 + (lane & 7), py = ty * 16 + qy * 8 + (lane >> 3);
+  const uint2 rg = reinterpret_cast<const uint2*>(ranges)[tile];
+  const bool in = py < H && px0 < W;
+  const size_t HW = (size_t)H * W;
+  const size_t pix0 = (size_t)py * W + px0;
+
+  float T, nTfin, la = 0.0f, bgdot, acc[3] = {0.0f, 0.0f, 0.0f}, lastc[3] = {0.0f, 0.0f, 0.0f}, gpx[3];
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  const float pxf = (float)px0, pyf = (float)py;
+  const float tf = in ? final_T[pix0] : 0.0f;
+  const uint32_t lastn = in ? n_contrib[pix0] : 0u;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) gpx[ch] = in ? dL_dpix[ch * HW + pix0] : 0.0f;
+  bgdot = (bg0 * gpx[0] + bg1 * gpx[1]) + bg2 * gpx[2];
+  T = tf; nTfin = -tf;
+  uint32_t maxn = lastn;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) maxn = max(maxn, (uint32_t)__shfl_xor((int)maxn, d, 64));
+  maxn = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxn);
+  if (maxn == 0) return;
+  const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+  const float wx0 = (float)(tx * 16 + qx * 8), wy0 = (float)(ty * 16 + qy * 8);   // this wave's pixel rectangle
+  const float wx1 = wx0 + 7.0f, wy1 = wy0 + 7.0f;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  // lanes that hold a result of wave_reduce9_swap, and where it goes in the row (accumulator-record order: conic A B C |
+  // opacity | mean x y | colour r g b); lanes 2 and 3 add the record's id and opacity to the same LDS store
+  const bool is_writer = (lane & 19) == 0 || lane == 1;
+  const int writer_val = lane == 1 ? 8 : 4 * (lane >> 5) + (((lane >> 2) & 1) << 1) + ((lane >> 3) & 1);
+  const int writer_comp = writer_val < 3 ? GGD_ACC_COLOR + writer_val
+                        : (writer_val < 6 ? GGD_ACC_CONIC + (writer_val - 3)
+                        : (writer_val < 8 ? GGD_ACC_MEAN2D + (writer_val - 6) : GGD_ACC_OPACITY));
+  const bool stores = is_writer || lane == 2 || lane == 3;
+  const int store_col = is_writer ? writer_comp : (lane == 2 ? 9 : 10);
+
+  // staged = the record as loaded with three words replaced in place:
+  //   {x, y, hA, nB} {hC, power threshold, opacity, 0-based list position} {g, b, r, Gaussian id}
+  bool keep = false;
+  uint32_t id_cur = 0, id_nxt = 0;
+  float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;    // x y hA nB | hC thr opacity r | g b ex ey
+  const uint32_t last_pos = rg.x + maxn - 1u;
+  auto round_start = [&](uint32_t ce) { return (ce - rg.x > 64u) ? ce - 64u : rg.x; };   // ce > rg.x
+  auto load_id = [&](uint32_t ce) {
+    const uint32_t cs = ce > rg.x ? round_start(ce) : rg.x;
+    id_nxt = list[min(cs + (uint32_t)lane, last_pos)];
+  };
+  auto load_rec = [&]() {
+    id_cur = id_nxt;
+    const float4* p = reinterpret_cast<const float4*>(splat + id_nxt);
+    r0 = p[0]; r1 = p[1]; r2 = p[2];
+  };
+  auto consume = [&](uint32_t ce) {
+    keep = false;
+    const uint32_t cs = round_start(ce);
+    if ((uint32_t)lane < ce - cs) {
+      keep = CULL ? (record_box_hits(r0.x, r0.y, r2.z, r2.w, wx0, wx1, wy0, wy1) &&
+                     record_reaches_block(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, wx0, wx1, wy0, wy1)) : true;
+      if (!CULL) r1.y = -__builtin_huge_valf();
+      r2.z = r1.w;
+      r1.w = __uint_as_float((cs - rg.x) + (uint32_t)lane);
+      r2.w = __uint_as_float(id_cur);
+    }
+  };
+  // the flush of one round's parked sums (cnt rows of buffer b)
+  auto flush = [&](int cnt) {
+    const float* rows = &s_sum[0][0];
+    for (int p = lane; p < cnt * 9; p += 64) {
+      const int r = p / 9, comp = p - 9 * r;
+      const float v = rows[r * 12 + comp];
+      const uint32_t id = __float_as_uint(rows[r * 12 + 9]);
+      const float op = rows[r * 12 + 10];
+      // d alpha / d G = opacity; d G / d conic = -1/2 G d d^T; the 0.5 W / 0.5 H of the pixel-to-NDC map and the minus sign
+      // of dG/d(delta) -- applied once per (record, component) here instead of per pixel
+      const float scale = comp < 3 ? -0.5f * op : (comp == 4 ? -op * ddelx_dx : (comp == 5 ? -op * ddely_dy : 1.0f));
+      atomicAdd(grad_acc + GGD_ACC_FLOATS * (size_t)id + comp, (comp < 3 || comp == 4 || comp == 5) ? scale * v : v);
+    }
+  };
+
+  uint32_t cend = rg.x + maxn;  // one past the last position this quarter needs
+  load_id(cend);
+  load_rec();
+  load_id(round_start(cend));
+  int prev_cnt = 0;
+  while (cend > rg.x) {
+    const uint32_t cstart = round_start(cend);
+    consume(cend);                                       // the records requested one round ago
+    __builtin_amdgcn_wave_barrier();                     // (the previous round's LDS reads are done: in-order per wave)
+    const uint64_t kept = __ballot(keep);
+    const int nk = __popcll(kept), n8 = (nk + 7) & ~7;
+    if (keep) {  // compacted, order preserved
+      const int slot = __popcll(kept & lt_mask);
+      s_rec[slot * 3 + 0] = r0; s_rec[slot * 3 + 1] = r1; s_rec[slot * 3 + 2] = r2;
+    }
+    if (lane >= nk && lane < n8) {   // padding: a record nobody sees
+      s_rec[lane * 3 + 0] = make_float4(0, 0, 0, 0);
+      s_rec[lane * 3 + 1] = make_float4(0, __builtin_huge_valf(), 0, 0);
+    }
+    flush(prev_cnt);                                     // the previous round's sums, BEFORE the new loads are issued
+    load_rec();                                          // next round's records
+    load_id(cstart > rg.x ? round_start(cstart) : rg.x); // and the list entries of the round after it
+    __builtin_amdgcn_wave_barrier();
+    int cnt = 0;
+    float* rows = &s_sum[0][0];
+    for (int j0 = n8 - 8; j0 >= 0; j0 -= 8) {
+      const float4* grp = s_rec + j0 * 3;
+#pragma unroll
+      for (int jj = 7; jj >= 0; --jj) {
+        const float4 a = grp[jj * 3 + 0], b = grp[jj * 3 + 1];
+        const float dy = a.y - pyf;
+        const float nBdy = a.w * dy, hCdy2 = (b.x * dy) * dy;
+        const uint32_t pos0 = __float_as_uint(b.w);
+        const float dx = a.x - pxf;
+        const float pw = __builtin_fmaf(__builtin_fmaf(a.z, dx, nBdy), dx, hCdy2);
+        const uint64_t need = __ballot(pos0 < lastn) & __ballot(pw >= b.y);
+        if (need == 0ull) continue;
+        const float4 c = grp[jj * 3 + 2];                            // g, b, r, Gaussian id
+        const float cA = -2.0f * a.z, cB = -a.w, cC = -2.0f * b.x;   // the conic (exact rescalings of hA, nB, hC)
+        const float col[3] = {c.z, c.x, c.y};
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sop;                  // colour r g b | conic A B C | mean x y ; opacity
+        // exact per-pixel visibility test, then alpha = G = 0 for pixels that do not see the record: every state update
+        // below is then an exact no-op for them (select-free recurrences)
+        const float g0 = blend_exp<EXP_MODE>(pw);
+        const float a0 = fminf(0.99f, b.z * g0);
+        const uint64_t live = need & ~__ballot(pw > 0.0f) & ~__ballot(a0 < ALPHA_FLOOR);
+        const float G = sel_or_zero(g0, live), alpha = sel_or_zero(a0, live);
+        const float om = 1.0f - alpha;
+        float inv = __builtin_amdgcn_rcpf(om);
+        inv = __builtin_fmaf(inv, __builtin_fmaf(-om, inv, 1.0f), inv);
+        T = T * inv;
+        const float dchannel_dcolor = alpha * T;
+        const float oml = 1.0f - la;
+        float dL_dalpha = 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          acc[ch] = __builtin_fmaf(la, lastc[ch], oml * acc[ch]);
+          asm volatile("v_mov_b32_e32 %0, %1" : "+v"(lastc[ch]) : "v"(col[ch]));   // in place (no copy on the culled path)
+          dL_dalpha = __builtin_fmaf(col[ch] - acc[ch], gpx[ch], dL_dalpha);
+          s[ch] = dchannel_dcolor * gpx[ch];
+        }
+        la = alpha;
+        dL_dalpha = __builtin_fmaf(nTfin * inv, bgdot, dL_dalpha * T);
+        const float gdx = G * dx, gdy = G * dy;
+        const float ex = __builtin_fmaf(gdy, cB, gdx * cA);   // -dG/d(delta x)
+        const float ey = __builtin_fmaf(gdx, cB, gdy * cC);   // -dG/d(delta y)
+        s[6] = dL_dalpha * ex;
+        s[7] = dL_dalpha * ey;
+        const float wx = gdx * dL_dalpha, wy = gdy * dL_dalpha;
+        s[3] = wx * dx;
+        s[4] = wx * dy;
+        s[5] = wy * dy;
+        sop = G * dL_dalpha;
+        if (live != 0ull) {   // wave-uniform: somebody in this wave saw the Gaussian
+          const float tot = wave_reduce9_swap(s, sop, 0x2222222222222222ull);
+          // writers: lanes 0,4,8,12 | 32,36,40,44 (component from the table above), lane 1 the opacity sum; lane 2 the
+          // Gaussian's id, lane 3 its opacity
+          const float v = is_writer ? tot : (lane == 2 ? c.w : b.z);
+          if (stores) rows[cnt * 12 + store_col] = v;
+          ++cnt;
+        }
+      }
+    }
+    prev_cnt = cnt;
+    cend = cstart;
+  }
+  __builtin_amdgcn_wave_barrier();
+  flush(prev_cnt);
+}
+
 }  // namespace
 
 int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
@@ -862,7 +1053,7 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
   const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
   const int T = gx * gy;
   const int split = ctx->opt[GGD_OPT_BLEND_SPLIT];   // 0: one wave per tile, 2: two (16x8), 3: four (8x8), 1: auto
-  const int nsub = split == 0 ? 1 : (split == 2 ? 2 : 4);
+  const int nsub = split == 0 ? 1 : (split == 2 ? 2 : 4);   // (4: the backward's quarter form; forward as 3)
 #define GGD_LAUNCH_FWD2(EM, CU, PX, BWID, ST)                                                                        \
   hipLaunchKernelGGL((blend_forward_kernel<EM, CU, PX, BWID, ST>), dim3(nsub * T), dim3(64), 0, s, prm.width,          \
                      prm.height, gx, T, splat, list, ranges, capacity, prm.bg, out_color, final_T, n_contrib,         \
@@ -900,6 +1091,19 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
   const int split = ctx->opt[GGD_OPT_BLEND_SPLIT];
   // 1 (auto) / 3: four 8x8 waves per tile in one workgroup; 2: two 16x8 waves per tile in one workgroup (per-record sums
   // combined in LDS: blend_backward_tile_kernel); 0: one wave per tile, 4 pixels per lane (blend_backward_kernel)
+  if (split == 4) {
+#define GGD_LAUNCH_BQ(EM, CU)                                                                                             \
+    hipLaunchKernelGGL((blend_backward_quarter_kernel<EM, CU>), dim3(4 * T), dim3(64), 0, s, prm.width, prm.height, gx,   \
+                       gy, splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc)
+    if (cull) {
+      if (em == 0) GGD_LAUNCH_BQ(0, true); else if (em == 1) GGD_LAUNCH_BQ(1, true); else GGD_LAUNCH_BQ(2, true);
+    } else {
+      if (em == 0) GGD_LAUNCH_BQ(0, false); else if (em == 1) GGD_LAUNCH_BQ(1, false); else GGD_LAUNCH_BQ(2, false);
+    }
+#undef GGD_LAUNCH_BQ
+    GGD_HIP(hipGetLastError());
+    return GGD_OK;
+  }
   if (split != 0) {
 #define GGD_LAUNCH_BT(EM, CU)                                                                                             \
     do {                                                                                                                  \

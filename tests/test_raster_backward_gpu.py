@@ -67,7 +67,7 @@ def test_backward_matches_oracle(native_lib, case):
         assert (nb["dL_dsh"].reshape(d["P"], -1, 3)[:, used:] == 0).all()   # coefficients above the active degree
 
 
-@pytest.mark.parametrize("split", [0, 2, 3])
+@pytest.mark.parametrize("split", [0, 2, 3, 4])
 @pytest.mark.parametrize("case", [dict(P=20000, size=256, kind="shell", lsm=-5.5), dict(P=4096, size=100, lsm=-5.0, width=100, height=52)],
                          ids=_ids)
 def test_backward_kernel_forms_match_oracle(native_lib, case, split):

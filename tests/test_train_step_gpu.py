@@ -142,7 +142,7 @@ def test_config3_size_trains(native_lib):
     batch = make_scene_batch(list(range(B)), N, S, dev, seed=0)
     curves = {}
     for name, kw in (("fp32", dict()), ("fused", dict(fused_decoder=True, fused_activations=True))):
-        tr = DecoderTrainer(dev, n_scenes_total=B, image_size=S, seed=11, lr=5e-3, perceptual_weight=0.05,
+        tr = DecoderTrainer(dev, n_scenes_total=B, image_size=S, seed=11, lr=1e-3, perceptual_weight=0.05,
                             perceptual_width_div=4, backbone_params=100_000, **kw)
         c = _curve(tr, steps, lambda it: batch)
         torch.cuda.synchronize()
