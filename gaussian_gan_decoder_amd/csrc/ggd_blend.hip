@@ -867,9 +867,9 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
     const uint32_t* __restrict__ ranges, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
   __shared__ float4 s_rec[64 * 3];
-  // [touched record, in processing order][9 sums | id | opacity | -]; ONE buffer: a round's rows are flushed at the top of the
+  // [touched record, in processing order][9 sums | id | opacity] (5888 B of LDS per wave with s_rec: 27 waves per CU); ONE buffer: a round's rows are flushed at the top of the
   // next round, before that round's first row is written (LDS operations of a wave execute in order)
-  __shared__ float s_sum[64][12];
+  __shared__ float s_sum[64][11];
   const int lane = threadIdx.x;
   int tile, sub;
   ggd_block_to_tile((int)blockIdx.x, 4, gx, gy, gx * gy, tile, sub);
@@ -942,9 +942,9 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
     const float* rows = &s_sum[0][0];
     for (int p = lane; p < cnt * 9; p += 64) {
       const int r = p / 9, comp = p - 9 * r;
-      const float v = rows[r * 12 + comp];
-      const uint32_t id = __float_as_uint(rows[r * 12 + 9]);
-      const float op = rows[r * 12 + 10];
+      const float v = rows[r * 11 + comp];
+      const uint32_t id = __float_as_uint(rows[r * 11 + 9]);
+      const float op = rows[r * 11 + 10];
       // d alpha / d G = opacity; d G / d conic = -1/2 G d d^T; the 0.5 W / 0.5 H of the pixel-to-NDC map and the minus sign
       // of dG/d(delta) -- applied once per (record, component) here instead of per pixel
       const float scale = comp < 3 ? -0.5f * op : (comp == 4 ? -op * ddelx_dx : (comp == 5 ? -op * ddely_dy : 1.0f));
@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
           // writers: lanes 0,4,8,12 | 32,36,40,44 (component from the table above), lane 1 the opacity sum; lane 2 the
           // Gaussian's id, lane 3 its opacity
           const float v = is_writer ? tot : (lane == 2 ? c.w : b.z);
-          if (stores) rows[cnt * 12 + store_col] = v;
+          if (stores) rows[cnt * 11 + store_col] = v;
           ++cnt;
         }
       }
