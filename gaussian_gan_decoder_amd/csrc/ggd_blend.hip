@@ -1088,9 +1088,13 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
   const int em = ctx->opt[GGD_OPT_EXP_MODE];
   const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
   const int T = gx * gy;
-  const int split = ctx->opt[GGD_OPT_BLEND_SPLIT];
-  // 1 (auto) / 3: four 8x8 waves per tile in one workgroup; 2: two 16x8 waves per tile in one workgroup (per-record sums
-  // combined in LDS: blend_backward_tile_kernel); 0: one wave per tile, 4 pixels per lane (blend_backward_kernel)
+  int split = ctx->opt[GGD_OPT_BLEND_SPLIT];
+  // 4: four INDEPENDENT 8x8 quarter waves per tile (blend_backward_quarter_kernel); 3: four 8x8 waves per tile in one
+  // workgroup, 2: two 16x8 waves per tile in one workgroup (per-record sums combined in LDS: blend_backward_tile_kernel);
+  // 0: one wave per tile, 4 pixels per lane (blend_backward_kernel).  1 (auto): the quarter form from 2048 tiles (8 waves per
+  // SIMD to draw from: 1 M / 1024^2 cube 375 -> 333 us, shell 744 -> 565 us), the tile form below (with 4 waves per SIMD the
+  // kernel is one wave's serial chain long, and the quarter form's wave flushes its sums alone: 500 k / 512^2 184 vs 206 us)
+  if (split == 1) split = T >= 2048 ? 4 : 3;
   if (split == 4) {
 #define GGD_LAUNCH_BQ(EM, CU)                                                                                             \
     hipLaunchKernelGGL((blend_backward_quarter_kernel<EM, CU>), dim3(4 * T), dim3(64), 0, s, prm.width, prm.height, gx,   \

@@ -205,9 +205,10 @@ enum {
                              1 (default) = auto: 3 on grids up to 64 x 64 tiles; on larger grids 2 from 2^20 instances, else 0.
                              debug=1 (key taps) or a tile grid beyond the LDS budget always uses 0 */
   GGD_OPT_BLEND_SPLIT = 3, /* blend kernels: 0 = one wave per 16x16 tile (4 px/lane), 2 = two waves per tile (16x8
-                             halves, 2 px/lane), 3 = four waves per tile (8x8 quarters, 1 px/lane), 1 (default) = auto
-                             (the measured best per kernel).  Forward results are identical; backward
-                             sums differ only in their fp32 summation order. */
+                             halves, 2 px/lane), 3 = four waves per tile (8x8 quarters, 1 px/lane; backward: the four in one
+                             workgroup, per-record sums combined in LDS), 4 = backward: four independent 8x8 quarter waves
+                             per tile (forward as 3), 1 (default) = auto (the measured best per kernel).
+                             Forward results are identical; backward sums differ only in their fp32 summation order. */
   GGD_OPT_COUNT
 };
 int ggd_set_option(ggd_ctx* ctx, int option, int value);
