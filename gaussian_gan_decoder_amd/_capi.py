@@ -116,10 +116,13 @@ class RasterError(RuntimeError):
 
 class Context:
     """One ggd_ctx (device workspace); not re-entrant, use one per (device, stream)."""
-    capacity_hint: dict  # (P, W, H) -> last num_rendered: sizes the binning buffer of the next single-call forward
+    capacity_hint: dict  # (P, W, H) -> decaying running maximum of num_rendered: sizes the binning buffer of the next
+    #                      single-call forward (rasterizer.rasterize_gaussians_native)
+    capacity_retries: int  # single-call forwards whose buffer was too small and that were redone in the exact two-call form
 
     def __init__(self, device_index: int):
         self.capacity_hint = {}
+        self.capacity_retries = 0
         self.lib = load()
         self.device_index = int(device_index)
         self.handle = self.lib.ggd_create(self.device_index)

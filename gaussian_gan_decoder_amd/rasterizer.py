@@ -79,6 +79,21 @@ def _sizes(kind: str, a: int, b: int) -> int:
     return v
 
 
+_HINT_DECAY = 0.98      # per frame: a one-off large frame is forgotten after ~100 frames (0.98^100 = 0.13)
+
+
+def _capacity(hint: int) -> int:
+    """Instances the binning buffer of a single-call forward is laid out for: 25 % + 64 k above the hint, rounded UP to the
+    next value of a geometric grid (2^(k/4)) so that the sizes repeat and the caching allocator reuses its blocks."""
+    want = int(hint * 1.25) + 65536
+    k = max(0, (want - 1).bit_length() - 1)            # 2^k <= want - 1 < 2^(k+1)
+    for q in (1.0, 1.189207115, 1.414213562, 1.681792831, 2.0):
+        cap = int(q * (1 << k)) + 1
+        if cap >= want:
+            return cap
+    return want
+
+
 class _NoGuard:
     def __enter__(self): return None
     def __exit__(self, *a): return False
@@ -163,15 +178,16 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
     with _device_guard(dev):
         binning = None
         if hint is not None and P > 0 and not debug:   # debug: exact two-call form, buffers laid out for num_rendered
-            # single-call forward: binning buffer sized from the previous frame of this shape (+25 %); the GPU does
+            # single-call forward: binning buffer sized from the recent frames of this shape (see _capacity); the GPU does
             # not wait for the num_rendered round trip.  Falls through to the exact two-phase path on overflow.
-            cap = int(hint * 1.25) + 65536
+            cap = _capacity(hint)
             binning = torch.empty((_sizes("b", cap, 0),), **u8)
             rc = lib.ggd_forward(ctx.handle, stream, C.byref(prm), _ptr(means3D), _ptr(sh_c), _ptr(col_c),
                                  _ptr(opacities), _ptr(sc_c), _ptr(rot_c), _ptr(cov_c), _ptr(geom), _ptr(radii),
                                  _ptr(binning), cap, _ptr(img), _ptr(color), C.byref(R))
             if rc == -6:       # GGD_E_CAPACITY: R is valid, redo the render phase with an exact buffer
                 binning = None
+                ctx.capacity_retries += 1
             else:
                 ctx.check(rc)
         else:
@@ -182,7 +198,10 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
             binning = torch.empty((lib.ggd_binning_bytes(R.value),), **u8)
             ctx.check(lib.ggd_forward_render(ctx.handle, stream, C.byref(prm), _ptr(geom), R.value, _ptr(binning),
                                              _ptr(img), _ptr(color)))
-    ctx.capacity_hint[key] = int(R.value)
+    # the hint is a DECAYING RUNNING MAXIMUM of num_rendered, not the last frame's value: consecutive scenes of a training
+    # step differ several-fold (the reference draws fov ~ U[5, 17] degrees per scene, target_dataloader.py:71), and with
+    # "last frame x 1.25" every upward swing took the overflow -> exact-retry path, i.e. a host sync
+    ctx.capacity_hint[key] = max(int(R.value), int((hint or 0) * _HINT_DECAY))
     return int(R.value), color, radii, geom, binning, img
 
 

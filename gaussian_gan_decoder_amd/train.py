@@ -18,8 +18,9 @@ What is kept exactly: decoder -> GaussianModel attribute assignment (:223-227) -
 (:232) -> L1 / L2 / SSIM / Sobel with the reference's weights (:36-40, :246-261) -> backward -> Adam (lr 9e-5, :32,213).
 
 Host-side design for N GPUs: the gradients of all parameters live in ONE persistent flat fp32 buffer (p.grad are views),
-cut into buckets of <= 32 MB; after backward every bucket's all-reduce is launched asynchronously and the Adam step of
-bucket k runs as soon as ITS all-reduce has finished (the later buckets are still in flight).  Optionally
+cut into communication units of <= 32 MB; a unit's all-reduce is launched asynchronously FROM INSIDE the backward, by a
+post-accumulate-grad hook, as soon as its last parameter's gradient is final (93 of the 119 MB -- the backbone's gradient
+-- at the very start of the backward), and the Adam step of bucket k runs as soon as ITS units have finished.  Optionally
 (scene_streams=True) the local scenes run on their own HIP streams, each with its own rasterizer context (ggd_ctx is
 per (device, stream)); measured, it brings nothing on top of the single-call forward (see __init__) and is off.
 """
@@ -119,6 +120,7 @@ class DecoderTrainer:
         self.params = self.decoder.get_params_custom() + [self.planes] + ([self.backbone] if self.backbone is not None else [])
         self.broadcast_parameters()
         self._setup_flat_gradients(lr)
+        self._setup_comm_units()
         if render_fn is None:
             from .gaussian_renderer import render_simple
             render_fn = render_simple
@@ -175,31 +177,73 @@ class DecoderTrainer:
             for p in self.params:
                 self.dist.broadcast(p.data, src=0, group=self.pg)
 
+    # ---- gradient all-reduce, overlapped with the backward ---------------------------------------------------------------
+    def _setup_comm_units(self):
+        """Cut the flat gradient into communication units (contiguous slices of <= BUCKET_BYTES) and register a
+        post-accumulate-grad hook on every parameter: a unit's all-reduce is launched -- asynchronously, from inside the
+        backward -- as soon as the LAST parameter overlapping it has its final gradient, so the collective runs under the
+        rest of the backward instead of after it (the reference all-reduces after the backward,
+        eg3d/training/training_loop.py:288-299; same result, the sum is only started earlier).  The bulk of the payload,
+        the backbone's gradient (93 of the 119 MB), is final at the very start of the backward; what remains at its end is
+        the decoder's + the planes' unit (26 MB).  Only set up when a process group with more than one rank exists."""
+        chunk = max(1, BUCKET_BYTES // 4)
+        self.units = []                       # [start, end, bucket index, params still missing this step, work]
+        self._units_of_param = {}
+        for k, (s, e, _) in enumerate(self.buckets):
+            for c0 in range(s, e, chunk):
+                self.units.append(dict(start=c0, end=min(e, c0 + chunk), bucket=k, need=0, missing=0, work=None))
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            mine = [u for u in self.units if u["start"] < off + n and u["end"] > off]
+            for u in mine:
+                u["need"] += 1
+            self._units_of_param[id(p)] = mine
+            off += n
+        self._hooks = []
+        if self.dist and self.world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._grad_ready))
+        self._arm_units()
+
+    def _arm_units(self):
+        for u in self.units:
+            u["missing"], u["work"] = u["need"], None
+        self._launched_bytes = 0
+
+    def _launch_unit(self, u):
+        u["work"] = self.dist.all_reduce(self.flat_grad[u["start"]:u["end"]], op=self.dist.ReduceOp.SUM, group=self.pg,
+                                         async_op=True)
+        self._launched_bytes += (u["end"] - u["start"]) * 4
+
+    def _grad_ready(self, p):
+        for u in self._units_of_param[id(p)]:
+            u["missing"] -= 1
+            if u["missing"] == 0 and u["work"] is None:
+                self._launch_unit(u)
+
     def allreduce_and_step(self):
-        """Launch every bucket's all-reduce (async), then per bucket: wait -> / world -> sanitise -> Adam.  Bucket k's Adam
-        runs while the all-reduces of buckets k+1.. are still in flight."""
+        """Per bucket: wait for its units' all-reduces (launched from the backward by the hooks; any unit a hook did not
+        reach -- a parameter without a gradient this step -- is launched here) -> / world -> sanitise -> Adam.  Bucket k's Adam
+        runs while the all-reduces of the later buckets are still in flight."""
         world = self.world
-        works = []
-        nbytes = 0
-        if self.dist and world > 1:
-            chunk = BUCKET_BYTES // 4
-            for (s, e, _) in self.buckets:
-                ws = []
-                for c0 in range(s, e, chunk):
-                    c1 = min(e, c0 + chunk)
-                    ws.append(self.dist.all_reduce(self.flat_grad[c0:c1], op=self.dist.ReduceOp.SUM, group=self.pg,
-                                                   async_op=True))
-                    nbytes += (c1 - c0) * 4
-                works.append(ws)
+        multi = bool(self.dist and world > 1)
+        if multi:
+            for u in self.units:
+                if u["work"] is None:
+                    self._launch_unit(u)
         for k, (s, e, _) in enumerate(self.buckets):
             g = self.flat_grad[s:e]
-            if works:
-                for w in works[k]:
-                    w.wait()
+            if multi:
+                for u in self.units:
+                    if u["bucket"] == k:
+                        u["work"].wait()
                 g /= world
             # the reference sanitises on every step, single-GPU runs included (eg3d/training/training_loop.py:288-299)
             torch.nan_to_num(g, nan=0.0, posinf=1e5, neginf=-1e5, out=g)
             self.optims[k].step()
+        nbytes = self._launched_bytes if multi else 0
+        self._arm_units()
         self.last_allreduce_bytes = nbytes
         return nbytes
 

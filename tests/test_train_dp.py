@@ -45,9 +45,20 @@ def _worker(rank, world, port, out_dir):
     tr = _make_trainer(world)
     assert len(tr.buckets) >= 2
     losses = []
+    total = sum(p.numel() for p in tr.params)
+    assert len(tr.units) >= len(tr.buckets) and sum(u["end"] - u["start"] for u in tr.units) == total
     for it in range(2):
         batch = make_scene_batch([rank], N_POINTS, CFG["image_size"], "cpu", seed=it)   # one scene per rank
-        losses.append(tr.step(batch))
+        # the step, taken apart: the all-reduces must already be in flight when the backward returns (launched by the
+        # post-accumulate-grad hooks), and the payload is every parameter exactly once whatever the number of ranks
+        tr.flat_grad.zero_()
+        loss = tr.local_loss(batch)
+        loss.backward()
+        in_flight = sum(u["work"] is not None for u in tr.units)
+        assert in_flight == len(tr.units), (in_flight, len(tr.units))
+        nbytes = tr.allreduce_and_step()
+        assert nbytes == 4 * total == tr.last_allreduce_bytes
+        losses.append(float(loss.detach()))
     flat = torch.cat([p.detach().reshape(-1) for p in tr.params])
     torch.save(dict(flat=flat, losses=losses), os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
@@ -153,3 +164,23 @@ def test_position_embedding_matches_the_reference_embedder():
         out = dec(planes, pos)
         assert out.xyz.shape == (pos.shape[0], 3) and torch.isfinite(out.color).all()
         out.xyz.sum().backward()
+
+
+def test_allreduce_payload_of_the_full_configuration():
+    """BASELINE config 5's payload: decoder 193 294 + shared planes 3 x 32 x 256 x 256 + the backbone stand-in = 29 763 294
+    floats (the reference's finetuned generator, sequential_decoder_reverse.py:89-99), i.e. 4 x 29 763 294 bytes per step,
+    cut into units of <= 32 MB that cover the flat gradient exactly once -- a property of the trainer, not of the rank count."""
+    from _cpu_render import render_simple_cpu
+    from _torch_losses import image_loss_torch
+    tr = DecoderTrainer("cpu", n_scenes_total=1, render_fn=render_simple_cpu, loss_fn=image_loss_torch,
+                        backbone_params=23_278_544)
+    total = sum(p.numel() for p in tr.params)
+    assert total == 29_763_294
+    assert tr.flat_grad.numel() == total
+    spans = sorted((u["start"], u["end"]) for u in tr.units)
+    assert spans[0][0] == 0 and spans[-1][1] == total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert max(e - s for s, e in spans) * 4 <= 32 << 20
+    assert sum(e - s for s, e in spans) * 4 == 4 * 29_763_294
+    # every parameter belongs to at least one unit, and a unit waits for exactly the parameters that overlap it
+    assert all(len(tr._units_of_param[id(p)]) >= 1 for p in tr.params)
+    assert sum(u["need"] for u in tr.units) == sum(len(v) for v in tr._units_of_param.values())
