@@ -21,7 +21,7 @@ enum {
 };
 
 enum { GGD_ATTR_MLP_FWD = 1, GGD_ATTR_MLP_BWD = 2, GGD_ATTR_MLP_WGRAD = 4, GGD_ATTR_TILEBIN = 8, GGD_ATTR_TRIPLANE32 = 16,
-       GGD_ATTR_TRIPLANE16 = 32 };
+       GGD_ATTR_TRIPLANE16 = 32, GGD_ATTR_MLP_HL = 64 };
 
 struct ggd_ctx {
   int device = 0;

@@ -300,6 +300,7 @@ __global__ __launch_bounds__(FWD_THREADS, FWD_WAVES / 4) void decoder_forward_ke
 #include "ggd_mlp_bwd.inc"
 #include "ggd_mlp_wgrad.inc"
 #include "ggd_mlp_pack.inc"
+#include "ggd_mlp_hl.inc"
 
 }  // namespace
 
@@ -441,6 +442,94 @@ extern "C" int ggd_decoder_backward_wgrad(ggd_ctx* ctx, void* stream, int32_t N,
     if (grid > 256) grid = 256;
     hipLaunchKernelGGL(decoder_backward_kernel, dim3(grid), dim3(MLP_THREADS), HEADT_BYTES, s, N, first, last,
                        static_cast<const unsigned char*>(packed_t), attrs, dattrs, static_cast<const __bf16*>(zbuf),
+                       static_cast<__bf16*>(dzbuf), dout, dfeat, dinfo);
+    int chunks = (n + 4 * WG_K - 1) / (4 * WG_K);
+    if (chunks > 128) chunks = 128;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(chunks, NHEAD * 4), dim3(WG_THREADS), WG_LDS, s, N, first, last,
+                       static_cast<const __bf16*>(zbuf), static_cast<const __bf16*>(dzbuf), dout, feat, pos, attrs, wgrad);
+  }
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
+// ---- the decoder at reference precision (split bf16 operands, csrc/ggd_mlp_hl.inc) -------------------------------------------
+extern "C" size_t ggd_decoder_packed_hl_bytes(void) { return (size_t)NHEAD * HLF_HEAD; }
+extern "C" size_t ggd_decoder_packed_t_hl_bytes(void) { return (size_t)NHEAD * HLT_HEAD; }
+
+extern "C" int ggd_decoder_pack_hl(ggd_ctx* ctx, void* stream, const float* const* params40, void* packed_hl,
+                                   void* packed_t_hl) {
+  if (!ctx) return GGD_E_INVALID;
+  if (!params40 || !packed_hl) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_pack_hl: NULL pointer");
+  ggd_pack_ptrs ptrs;
+  for (int i = 0; i < NHEAD * 8; ++i) {
+    if (!params40[i]) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_pack_hl: NULL parameter pointer");
+    ptrs.p[i] = params40[i];
+  }
+  const int total = NHEAD * HLPK_PER_HEAD;
+  hipLaunchKernelGGL(decoder_pack_hl_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), ptrs,
+                     static_cast<unsigned char*>(packed_hl), static_cast<unsigned char*>(packed_t_hl));
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
+static int hl_attributes(ggd_ctx* ctx) {
+  if (ctx->attr_mask & GGD_ATTR_MLP_HL) return GGD_OK;
+  GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_forward_hl_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HL_LDS_FWD));
+  GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_forward_hl_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HL_LDS_FWD));
+  GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_backward_hl_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HL_LDS_BWD));
+  GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_wgrad_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
+  ctx->attr_mask |= GGD_ATTR_MLP_HL | GGD_ATTR_MLP_WGRAD;
+  return GGD_OK;
+}
+
+extern "C" int ggd_decoder_forward_hl(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
+                                      const void* packed_hl, float* attrs, void* zbuf) {
+  if (!ctx) return GGD_E_INVALID;
+  if (N < 0) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_forward_hl: N < 0");
+  if (N == 0) return GGD_OK;
+  if (!feat || !pos || !packed_hl || !attrs) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_forward_hl: NULL pointer");
+  const int rc = hl_attributes(ctx);
+  if (rc != GGD_OK) return rc;
+  int grid = (N + FWD_WAVES * SLAB - 1) / (FWD_WAVES * SLAB);
+  if (grid > 256) grid = 256;
+  if (zbuf)
+    hipLaunchKernelGGL(decoder_forward_hl_kernel<true>, dim3(grid), dim3(FWD_THREADS), HL_LDS_FWD,
+                       static_cast<hipStream_t>(stream), feat, pos, N, static_cast<const unsigned char*>(packed_hl), attrs,
+                       static_cast<__bf16*>(zbuf));
+  else
+    hipLaunchKernelGGL(decoder_forward_hl_kernel<false>, dim3(grid), dim3(FWD_THREADS), HL_LDS_FWD,
+                       static_cast<hipStream_t>(stream), feat, pos, N, static_cast<const unsigned char*>(packed_hl), attrs,
+                       (__bf16*)nullptr);
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
+extern "C" int ggd_decoder_backward_wgrad_hl(ggd_ctx* ctx, void* stream, int32_t N, int32_t chunk, const void* packed_t_hl,
+                                             const float* attrs, const float* dattrs, const void* zbuf, void* dzbuf,
+                                             float* dout, float* dfeat, float* dinfo, const float* feat, const float* pos,
+                                             float* wgrad) {
+  if (!ctx) return GGD_E_INVALID;
+  if (N < 0) return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_backward_wgrad_hl: N < 0");
+  if (N == 0) return GGD_OK;
+  if (!packed_t_hl || !attrs || !dattrs || !zbuf || !dzbuf || !dout || !dfeat || !dinfo || !feat || !pos || !wgrad)
+    return ggd_fail(ctx, GGD_E_INVALID, "ggd_decoder_backward_wgrad_hl: NULL pointer");
+  const int rc = hl_attributes(ctx);
+  if (rc != GGD_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (chunk <= 0 || chunk > N) chunk = N;
+  chunk = (chunk + 255) / 256 * 256;
+  for (int32_t first = 0; first < N; first += chunk) {
+    const int32_t last = first + chunk < N ? first + chunk : N;
+    const int32_t n = last - first;
+    int grid = (n + MLP_WAVES * SLAB - 1) / (MLP_WAVES * SLAB);
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL(decoder_backward_hl_kernel, dim3(grid), dim3(MLP_THREADS), HL_LDS_BWD, s, N, first, last,
+                       static_cast<const unsigned char*>(packed_t_hl), attrs, dattrs, static_cast<const __bf16*>(zbuf),
                        static_cast<__bf16*>(dzbuf), dout, dfeat, dinfo);
     int chunks = (n + 4 * WG_K - 1) / (4 * WG_K);
     if (chunks > 128) chunks = 128;

@@ -129,10 +129,20 @@ def _splitk_dw(dy: torch.Tensor, x: torch.Tensor, chunk: int = 4096) -> torch.Te
     return dw
 
 
-def device_pack(decoder, params=None, buffers=None):
+PRECISIONS = ("bf16", "fp32")
+
+
+def _check_precision(precision: str) -> bool:
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS} (got {precision!r})")
+    return precision == "fp32"
+
+
+def device_pack(decoder, params=None, buffers=None, hl: bool = False):
     """(packed, packed_t) built by the library's pack kernel from the decoder's 40 parameter tensors (head order colour,
-    opacity, rotation, scale, xyz; W1 b1 .. W4 b4).  Same bytes as pack_weights / pack_weights_t, which stay the host-side
-    statement of the format.  `buffers`: a previous result to overwrite in place."""
+    opacity, rotation, scale, xyz; W1 b1 .. W4 b4).  hl=False: the bf16 images -- same bytes as pack_weights /
+    pack_weights_t, which stay the host-side statement of that format; hl=True: the split (hi + lo) images of the
+    reference-precision kernels (csrc/ggd_mlp_hl.inc).  `buffers`: a previous result to overwrite in place."""
     if params is None:
         params = [t for head in _head_tensors(decoder) for t in head]
     dev = params[0].device
@@ -141,13 +151,16 @@ def device_pack(decoder, params=None, buffers=None):
     ps = [p.detach() for p in params]
     ps = [p if (p.dtype == torch.float32 and p.is_contiguous()) else p.float().contiguous() for p in ps]
     cx = _capi.context_for(dev)
-    if buffers is None or buffers[0].device != dev:
-        buffers = (torch.empty((cx.lib.ggd_decoder_packed_bytes(),), dtype=torch.uint8, device=dev),
-                   torch.empty((cx.lib.ggd_decoder_packed_t_bytes(),), dtype=torch.uint8, device=dev))
+    sizes = ((cx.lib.ggd_decoder_packed_hl_bytes(), cx.lib.ggd_decoder_packed_t_hl_bytes()) if hl else
+             (cx.lib.ggd_decoder_packed_bytes(), cx.lib.ggd_decoder_packed_t_bytes()))
+    if buffers is None or buffers[0].device != dev or buffers[0].numel() != sizes[0]:
+        buffers = (torch.empty((sizes[0],), dtype=torch.uint8, device=dev),
+                   torch.empty((sizes[1],), dtype=torch.uint8, device=dev))
     table = (C.c_void_p * 40)(*[p.data_ptr() for p in ps])
+    fn = cx.lib.ggd_decoder_pack_hl if hl else cx.lib.ggd_decoder_pack
     with torch.cuda.device(dev):
-        cx.check(cx.lib.ggd_decoder_pack(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), table,
-                                         C.c_void_p(buffers[0].data_ptr()), C.c_void_p(buffers[1].data_ptr())))
+        cx.check(fn(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), table,
+                    C.c_void_p(buffers[0].data_ptr()), C.c_void_p(buffers[1].data_ptr())))
     return buffers
 
 
@@ -163,7 +176,7 @@ class FusedDecoderFn(torch.autograd.Function):
     GEMMs over the kept pre-activations (bf16)."""
 
     @staticmethod
-    def forward(ctx, feats, pos, packed, packed_t, *params):
+    def forward(ctx, feats, pos, packed, packed_t, hl, *params):
         dev = feats.device
         feats = feats.contiguous().float()
         pos = pos.contiguous().float()
@@ -171,13 +184,14 @@ class FusedDecoderFn(torch.autograd.Function):
         cx = _capi.context_for(dev)
         attrs = torch.empty((n, 16), dtype=torch.float32, device=dev)
         zbuf = torch.empty((5, 3, (n + 15) // 16 * 16, HID), dtype=torch.bfloat16, device=dev)   # 16-point blocks (ggd_decoder_zbuf_bytes)
+        fwd = cx.lib.ggd_decoder_forward_hl if hl else cx.lib.ggd_decoder_forward_train
         with torch.cuda.device(dev):
-            cx.check(cx.lib.ggd_decoder_forward_train(
-                cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), C.c_void_p(feats.data_ptr()),
-                C.c_void_p(pos.data_ptr()), n, C.c_void_p(packed.data_ptr()), C.c_void_p(attrs.data_ptr()),
-                C.c_void_p(zbuf.data_ptr())))
+            cx.check(fwd(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), C.c_void_p(feats.data_ptr()),
+                         C.c_void_p(pos.data_ptr()), n, C.c_void_p(packed.data_ptr()), C.c_void_p(attrs.data_ptr()),
+                         C.c_void_p(zbuf.data_ptr())))
         ctx.save_for_backward(feats, pos, attrs, zbuf, packed_t)
         ctx.param_shapes = [tuple(p.shape) for p in params]
+        ctx.hl = bool(hl)
         return attrs
 
     @staticmethod
@@ -195,8 +209,9 @@ class FusedDecoderFn(torch.autograd.Function):
         wg = torch.zeros((5, per_head), dtype=torch.float32, device=dev)
         # activation backward + weight gradients, chunk by chunk (WGRAD_CHUNK points): a chunk's dz / z rows are consumed by
         # the weight-gradient kernel while they are still in the Infinity Cache
+        bwd = cx.lib.ggd_decoder_backward_wgrad_hl if ctx.hl else cx.lib.ggd_decoder_backward_wgrad
         with torch.cuda.device(dev):
-            cx.check(cx.lib.ggd_decoder_backward_wgrad(
+            cx.check(bwd(
                 cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), n, int(WGRAD_CHUNK),
                 C.c_void_p(packed_t.data_ptr()), C.c_void_p(attrs.data_ptr()), C.c_void_p(dattrs.data_ptr()),
                 C.c_void_p(zbuf.data_ptr()), C.c_void_p(dzbuf.data_ptr()), C.c_void_p(dout.data_ptr()),
@@ -212,7 +227,7 @@ class FusedDecoderFn(torch.autograd.Function):
                 o += rows * cols
                 grads += [w, wg[h, o:o + rows][:r_used]]
                 o += rows
-        return (dfeat, None, None, None, *grads)
+        return (dfeat, None, None, None, None, *grads)
 
 
 class _SplitAttrs(torch.autograd.Function):
@@ -253,10 +268,15 @@ class FusedTrainDecoder(torch.nn.Module):
     """Training front-end with the `SequentialDecoderReverse` call signature: tri-plane gather (HIP) + the fused
     bf16-MFMA decoder with autograd.  Wraps (and shares the parameters of) a SequentialDecoderReverse."""
 
-    def __init__(self, decoder: SequentialDecoderReverse):
+    def __init__(self, decoder: SequentialDecoderReverse, precision: str = "bf16"):
+        """precision: "bf16" = operands rounded to bf16 (outputs within 5e-2, parameter gradients within 5-6 % of fp32);
+        "fp32" = the reference's training precision on the same matrix cores: split bf16 operands, three MFMAs per product
+        (outputs within 1e-4, parameter gradients within 1e-3 relative L2 of the fp32 module)."""
         super().__init__()
         self.decoder = decoder
         _check_decoder(decoder)
+        self.precision = precision
+        self._hl = _check_precision(precision)
         self._image_bufs = None
 
     def get_params_custom(self):
@@ -266,7 +286,7 @@ class FusedTrainDecoder(torch.nn.Module):
         """Weight images for this call: ONE device launch (ggd_decoder_pack) straight from the parameter tensors, on every
         forward.  (They used to be cached on the parameters' `_version`; torch's fused Adam updates parameters without
         bumping it, so a trainer kept decoding with the images of step 0.)"""
-        packed, packed_t = device_pack(self.decoder, params, self._image_bufs)
+        packed, packed_t = device_pack(self.decoder, params, self._image_bufs, self._hl)
         self._image_bufs = (packed, packed_t)
         return packed, packed_t
 
@@ -278,7 +298,7 @@ class FusedTrainDecoder(torch.nn.Module):
                                          self.decoder.triplane_depth) for b in range(B)], dim=0)
         params = [t for head in _head_tensors(self.decoder) for t in head]
         packed, packed_t = self._images(params)
-        a = FusedDecoderFn.apply(feats, positions.reshape(B * N, 3), packed, packed_t, *params)
+        a = FusedDecoderFn.apply(feats, positions.reshape(B * N, 3), packed, packed_t, self._hl, *params)
         return a.view(B, N, 16)
 
     def forward(self, feature_planes, init_position):
@@ -286,12 +306,14 @@ class FusedTrainDecoder(torch.nn.Module):
                               self.decoder.triplane_depth)
         params = [t for head in _head_tensors(self.decoder) for t in head]
         packed, packed_t = self._images(params)
-        a = FusedDecoderFn.apply(feats, init_position, packed, packed_t, *params)
+        a = FusedDecoderFn.apply(feats, init_position, packed, packed_t, self._hl, *params)
         return SimpleNamespace(color=a[:, 0:3], opacity=a[:, 3:4], rotation=a[:, 4:8], scale=a[:, 8:11], xyz=a[:, 11:14])
 
 
 class FusedDecoder:
-    def __init__(self, decoder: SequentialDecoderReverse):
+    def __init__(self, decoder: SequentialDecoderReverse, precision: str = "bf16"):
+        self.precision = precision
+        self._hl = _check_precision(precision)
         self.decoder = decoder
         self.box_warp = decoder.box_warp
         self.plane_axes, self.triplane_depth = decoder.plane_axes, decoder.triplane_depth
@@ -300,7 +322,9 @@ class FusedDecoder:
     def repack(self):
         """Rebuild the weight image after the wrapped decoder's parameters changed."""
         if next(self.decoder.parameters()).is_cuda:
-            self.packed = device_pack(self.decoder)[0]
+            self.packed = device_pack(self.decoder, hl=self._hl)[0]
+        elif self._hl:
+            raise RuntimeError("the fused decoder is a HIP kernel: move the decoder to the GPU first")
         else:
             self.packed = pack_weights(self.decoder)
 
@@ -315,10 +339,16 @@ class FusedDecoder:
         n = positions.shape[0]
         attrs = torch.empty((n, 16), dtype=torch.float32, device=dev)
         cx = _capi.context_for(dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
-            cx.check(cx.lib.ggd_decoder_forward(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
-                                                C.c_void_p(feats.data_ptr()), C.c_void_p(positions.data_ptr()), n,
-                                                C.c_void_p(self.packed.data_ptr()), C.c_void_p(attrs.data_ptr())))
+            if self._hl:
+                cx.check(cx.lib.ggd_decoder_forward_hl(cx.handle, stream, C.c_void_p(feats.data_ptr()),
+                                                       C.c_void_p(positions.data_ptr()), n,
+                                                       C.c_void_p(self.packed.data_ptr()), C.c_void_p(attrs.data_ptr()), None))
+            else:
+                cx.check(cx.lib.ggd_decoder_forward(cx.handle, stream, C.c_void_p(feats.data_ptr()),
+                                                    C.c_void_p(positions.data_ptr()), n,
+                                                    C.c_void_p(self.packed.data_ptr()), C.c_void_p(attrs.data_ptr())))
         return attrs
 
     @torch.no_grad()

@@ -80,7 +80,7 @@ class DecoderTrainer:
                  l1_weight: float = 0.2, l2_weight: float = 0.1, ssim_weight: float = 0.5, sobel_weight: float = 0.2,
                  loss_fn=None, process_group=None, fused_activations: bool = False, fused_decoder: bool = False,
                  backbone_params: int = 0, perceptual_weight: float = 0.0, perceptual_width_div: int = 1,
-                 scene_streams: bool = False):
+                 scene_streams: bool = False, decoder_precision: str = "bf16"):
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.pg = process_group
@@ -111,12 +111,13 @@ class DecoderTrainer:
             self.perceptual = PerceptualStandIn(seed=seed + 99, width_div=perceptual_width_div).to(self.device)
             if self.device.type == "cuda":
                 self.perceptual = self.perceptual.to(memory_format=torch.channels_last)
-        # fused_decoder: bf16-MFMA decoder kernels (forward + activation backward) instead of the PyTorch module
+        # fused_decoder: the MFMA decoder kernels (forward, activation backward, weight gradients) instead of the PyTorch
+        # module; decoder_precision "bf16" (operands rounded to bf16) or "fp32" (split operands: the reference's precision)
         self.decoder_fwd = self.decoder
         self.fused_decoder = bool(fused_decoder)
         if fused_decoder:
             from .fused_decoder import FusedTrainDecoder
-            self.decoder_fwd = FusedTrainDecoder(self.decoder)
+            self.decoder_fwd = FusedTrainDecoder(self.decoder, precision=decoder_precision)
         self.params = self.decoder.get_params_custom() + [self.planes] + ([self.backbone] if self.backbone is not None else [])
         self.broadcast_parameters()
         self._setup_flat_gradients(lr)

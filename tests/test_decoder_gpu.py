@@ -183,3 +183,90 @@ def test_fused_train_decoder_follows_an_optimizer_step(native_lib):
         now = fused(planes, pos).color
     assert (outs[1] - outs[0]).abs().max().item() > 1e-3 and (outs[2] - outs[1]).abs().max().item() > 1e-3
     assert (now - ref).abs().max().item() <= 5e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("N", [1, 33, 5000, 100003, 1_000_000])
+def test_fused_decoder_fp32_precision_matches_the_fp32_module(native_lib, N):
+    """precision="fp32" (split bf16 operands, three MFMAs per product, csrc/ggd_mlp_hl.inc): every output within 1e-4 of the
+    fp32 PyTorch module (the bf16 form is only held to 5e-2) -- the reference trains and evaluates its decoder in fp32
+    (main/decoder_models/base_decoder.py:8-27)."""
+    from gaussian_gan_decoder_amd.fused_decoder import FusedDecoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    dec = SequentialDecoderReverse().to(dev)
+    for p in dec.parameters():            # make the heads' outputs O(1) so the comparison is meaningful
+        if p.dim() == 2:
+            p.data *= 1.5
+    planes = torch.randn(3, 32, 64, 64, device=dev)
+    pos = torch.rand(N, 3, device=dev) - 0.5
+    out = FusedDecoder(dec, precision="fp32")(planes, pos)
+    with torch.no_grad():
+        ref = dec.double()(planes.double(), pos.double())
+    worst = 0.0
+    for name in ("color", "opacity", "rotation", "scale", "xyz"):
+        got, want = getattr(out, name), getattr(ref, name)
+        assert got.shape == want.shape, name
+        err = (got.double() - want).abs().max().item() / max(1.0, want.abs().max().item())
+        worst = max(worst, err)
+        assert err <= 1e-4, (name, err)
+    print(f"\n  N = {N}: max scaled |fused fp32 - float64 module| = {worst:.2e}")
+
+
+def test_fused_decoder_fp32_precision_matches_reference_class_fixture(native_lib):
+    """precision="fp32" against the outputs of the reference's own SequentialDecoderReverse (fp32; sequential_decoder_fixture.npz):
+    1e-4 (the fp32 PyTorch path on the GPU is held to 2e-5, the bf16 kernel to 5e-2)."""
+    import os
+    import numpy as np
+    from gaussian_gan_decoder_amd.fused_decoder import FusedDecoder
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sequential_decoder_fixture.npz"))
+    dev = torch.device("cuda:0")
+    dec = SequentialDecoderReverse()
+    dec.load_state_dict({k[len("sd_"):]: torch.from_numpy(f[k]) for k in f.files if k.startswith("sd_")}, strict=False)
+    dec = dec.to(dev)
+    planes, pos = torch.from_numpy(f["planes"]).to(dev), torch.from_numpy(f["positions"]).to(dev)
+    with torch.no_grad():
+        o = FusedDecoder(dec, precision="fp32")(planes, pos)
+    for k in ("color", "opacity", "rotation", "scale", "xyz"):
+        ref = f[k]
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(getattr(o, k).cpu().numpy() - ref).max()) <= 1e-4 * scale, k
+
+
+def test_fused_decoder_fp32_precision_training_gradients(native_lib):
+    """FusedTrainDecoder(precision="fp32") vs float64 autograd of the same module: outputs within 1e-4, every parameter
+    gradient and the plane gradient within 1e-3 relative L2 (the bf16 form: 5e-2 / 6e-2)."""
+    from gaussian_gan_decoder_amd.fused_decoder import FusedTrainDecoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    ref = SequentialDecoderReverse().to(dev)
+    for p in ref.parameters():
+        if p.dim() == 2:
+            p.data *= 1.5
+    fused_mod = SequentialDecoderReverse().to(dev)
+    fused_mod.load_state_dict(ref.state_dict())
+    ref = ref.double()
+    fused = FusedTrainDecoder(fused_mod, precision="fp32")
+    N = 200_003
+    planes_a = torch.randn(3, 32, 64, 64, device=dev, dtype=torch.float64, requires_grad=True)
+    planes_b = planes_a.detach().float().requires_grad_(True)
+    pos = torch.rand(N, 3, device=dev) - 0.5
+    g = torch.Generator().manual_seed(4)
+    w = {k: torch.randn(N, d, generator=g).to(dev) for k, d in (("color", 3), ("opacity", 1), ("rotation", 4), ("scale", 3), ("xyz", 3))}
+
+    def loss(o):
+        return sum((getattr(o, k) * w[k].to(getattr(o, k).dtype)).sum() for k in w) / N
+    oa = ref(planes_a, pos.double()); loss(oa).backward()
+    ob = fused(planes_b, pos); loss(ob).backward()
+    for k in w:
+        a, b = getattr(oa, k), getattr(ob, k).double()
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item()), k
+
+    def rel(a, b):
+        return ((a - b.double()).norm() / (a.norm() + 1e-30)).item()
+    report = [("planes", rel(planes_a.grad, planes_b.grad))]
+    for (na, pa), (nb, pb) in zip(ref.named_parameters(), fused_mod.named_parameters()):
+        assert pb.grad is not None, nb
+        report.append((na, rel(pa.grad, pb.grad)))
+    print("\n  relative L2 error of the gradients: max %.2e (%s), planes %.2e" % (max(r for _, r in report), max(report, key=lambda t: t[1])[0], report[0][1]))
+    for name, r in report:
+        assert r <= 1e-3, (name, r)
