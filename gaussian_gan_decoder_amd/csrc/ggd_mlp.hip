@@ -455,6 +455,7 @@ extern "C" int ggd_decoder_backward_wgrad(ggd_ctx* ctx, void* stream, int32_t N,
 
 // ---- the decoder at reference precision (split bf16 operands, csrc/ggd_mlp_hl.inc) -------------------------------------------
 extern "C" size_t ggd_decoder_packed_hl_bytes(void) { return (size_t)NHEAD * HLF_HEAD; }
+extern "C" size_t ggd_decoder_zbuf_hl_bytes(int32_t N) { return 2 * ggd_decoder_zbuf_bytes(N); }   // hi plane | lo plane
 extern "C" size_t ggd_decoder_packed_t_hl_bytes(void) { return (size_t)NHEAD * HLT_HEAD; }
 
 extern "C" int ggd_decoder_pack_hl(ggd_ctx* ctx, void* stream, const float* const* params40, void* packed_hl,
@@ -481,9 +482,9 @@ static int hl_attributes(ggd_ctx* ctx) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)HL_LDS_FWD));
   GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_backward_hl_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)HL_LDS_BWD));
-  GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_wgrad_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
-  ctx->attr_mask |= GGD_ATTR_MLP_HL | GGD_ATTR_MLP_WGRAD;
+  GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_wgrad_hl_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WGH_LDS));
+  ctx->attr_mask |= GGD_ATTR_MLP_HL;
   return GGD_OK;
 }
 
@@ -534,7 +535,7 @@ extern "C" int ggd_decoder_backward_wgrad_hl(ggd_ctx* ctx, void* stream, int32_t
     int chunks = (n + 4 * WG_K - 1) / (4 * WG_K);
     if (chunks > 128) chunks = 128;
     if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(chunks, NHEAD * 4), dim3(WG_THREADS), WG_LDS, s, N, first, last,
+    hipLaunchKernelGGL(decoder_wgrad_hl_kernel, dim3(chunks, NHEAD * 4), dim3(WG_THREADS), WGH_LDS, s, N, first, last,
                        static_cast<const __bf16*>(zbuf), static_cast<const __bf16*>(dzbuf), dout, feat, pos, attrs, wgrad);
   }
   GGD_HIP(hipGetLastError());

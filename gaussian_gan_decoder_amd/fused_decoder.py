@@ -183,7 +183,8 @@ class FusedDecoderFn(torch.autograd.Function):
         n = pos.shape[0]
         cx = _capi.context_for(dev)
         attrs = torch.empty((n, 16), dtype=torch.float32, device=dev)
-        zbuf = torch.empty((5, 3, (n + 15) // 16 * 16, HID), dtype=torch.bfloat16, device=dev)   # 16-point blocks (ggd_decoder_zbuf_bytes)
+        planes = 2 if hl else 1     # reference precision: z kept as two bf16 planes (hi | lo)
+        zbuf = torch.empty((planes, 5, 3, (n + 15) // 16 * 16, HID), dtype=torch.bfloat16, device=dev)   # 16-point blocks (ggd_decoder_zbuf_bytes)
         fwd = cx.lib.ggd_decoder_forward_hl if hl else cx.lib.ggd_decoder_forward_train
         with torch.cuda.device(dev):
             cx.check(fwd(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), C.c_void_p(feats.data_ptr()),
@@ -201,7 +202,7 @@ class FusedDecoderFn(torch.autograd.Function):
         n = pos.shape[0]
         dattrs = dattrs.contiguous().float()
         cx = _capi.context_for(dev)
-        dzbuf = torch.empty((5, 3, (n + 15) // 16 * 16, HID), dtype=torch.bfloat16, device=dev)
+        dzbuf = torch.empty_like(zbuf)
         dout = torch.empty((5, n, 4), dtype=torch.float32, device=dev)
         dfeat = torch.empty((n, 32), dtype=torch.float32, device=dev)
         dinfo = torch.empty((n, 16), dtype=torch.float32, device=dev)

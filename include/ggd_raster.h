@@ -330,13 +330,15 @@ int ggd_decoder_backward_wgrad(ggd_ctx* ctx, void* stream, int32_t N, int32_t ch
 /*
  * The fused decoder at REFERENCE PRECISION (the reference trains its decoder in fp32, main/decoder_models/base_decoder.py:8-27):
  * same kernels' structure on the bf16 matrix cores with every fp32 operand split into two bf16 numbers (x = hi + lo) and
- * every product evaluated as W_hi x_hi + W_hi x_lo + W_lo x_hi with fp32 accumulation (csrc/ggd_mlp_hl.inc).  Forward:
- * weights and activations split (outputs within 1e-5 of an fp32 evaluation); backward: weights split, dz as one bf16.
+ * every product evaluated as W_hi x_hi + W_hi x_lo + W_lo x_hi with fp32 accumulation (csrc/ggd_mlp_hl.inc), in the forward,
+ * the backward and the weight gradients (outputs within 1e-5 of an fp32 evaluation).
  * The weight images have their own format (hi and lo image per layer): ggd_decoder_pack_hl builds both from the 40
- * parameter tensors (see ggd_decoder_pack).  zbuf / dzbuf / dout / dfeat / dinfo / wgrad as in the bf16 entry points
- * (ggd_decoder_forward_hl with zbuf == NULL is the inference form).
+ * parameter tensors (see ggd_decoder_pack).  zbuf and dzbuf hold TWO bf16 planes each (hi | lo, ggd_decoder_zbuf_hl_bytes(N) =
+ * 2 x ggd_decoder_zbuf_bytes(N)); dout / dfeat / dinfo / wgrad as in the bf16 entry points (ggd_decoder_forward_hl with
+ * zbuf == NULL is the inference form).
  */
 size_t ggd_decoder_packed_hl_bytes(void);
+size_t ggd_decoder_zbuf_hl_bytes(int32_t N);
 size_t ggd_decoder_packed_t_hl_bytes(void);
 int ggd_decoder_pack_hl(ggd_ctx* ctx, void* stream, const float* const* params40, void* packed_hl, void* packed_t_hl);
 int ggd_decoder_forward_hl(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
