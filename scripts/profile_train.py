@@ -4,7 +4,8 @@ import torch
 from gaussian_gan_decoder_amd.train import DecoderTrainer, make_scene_batch
 dev = torch.device('cuda:0')
 fused = '--fused' in sys.argv
-tr = DecoderTrainer(dev, n_scenes_total=4, image_size=512, fused_activations=True, fused_decoder=fused)
+tr = DecoderTrainer(dev, n_scenes_total=4, image_size=512, fused_activations=True, fused_decoder=fused,
+                    decoder_precision='fp32' if '--fp32' in sys.argv else 'bf16')
 b = make_scene_batch([0,1,2,3], 500000, 512, dev, seed=0)
 for _ in range(2): tr.step(b)
 torch.cuda.synchronize()

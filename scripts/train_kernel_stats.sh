@@ -2,7 +2,7 @@
 # Per-kernel GPU time of one fused-decoder train step (rocprofv3 kernel trace of scripts/profile_train.py --fused).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rm -rf /tmp/pt; rocprofv3 --kernel-trace --stats -d /tmp/pt -o p --output-format csv -- python $R/scripts/profile_train.py --fused > /tmp/pt.log 2>&1
+rm -rf /tmp/pt; rocprofv3 --kernel-trace --stats -d /tmp/pt -o p --output-format csv -- python $R/scripts/profile_train.py --fused $1 > /tmp/pt.log 2>&1
 python - <<'PY'
 import csv
 rows = list(csv.DictReader(open("/tmp/pt/p_kernel_stats.csv")))
