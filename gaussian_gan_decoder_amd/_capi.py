@@ -19,7 +19,7 @@ EXPORTS = [
     "ggd_img_layout", "ggd_sort_bits", "ggd_create", "ggd_destroy", "ggd_last_error", "ggd_version",
     "ggd_forward_geometry", "ggd_forward_render", "ggd_forward", "ggd_forward_can_speculate", "ggd_backward", "ggd_mark_visible", "ggd_debug_unsorted",
     "ggd_triplane_forward", "ggd_triplane_backward", "ggd_trigrid_forward", "ggd_trigrid_backward", "ggd_surface_tmp_bytes", "ggd_surface_sample", "ggd_decoder_packed_bytes", "ggd_decoder_pack", "ggd_decoder_forward", "ggd_decoder_zbuf_bytes", "ggd_decoder_packed_t_bytes",
-    "ggd_decoder_forward_train", "ggd_decoder_backward", "ggd_decoder_wgrad_floats", "ggd_decoder_wgrad", "ggd_decoder_backward_wgrad", "ggd_decoder_packed_hl_bytes", "ggd_decoder_packed_t_hl_bytes", "ggd_decoder_zbuf_hl_bytes", "ggd_decoder_pack_hl", "ggd_decoder_forward_hl", "ggd_decoder_backward_wgrad_hl", "ggd_image_loss_tmp_bytes", "ggd_image_loss", "ggd_set_option", "ggd_get_option", "ggd_blend_stats", "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
+    "ggd_decoder_forward_train", "ggd_decoder_backward", "ggd_decoder_wgrad_floats", "ggd_decoder_wgrad", "ggd_decoder_backward_wgrad", "ggd_decoder_packed_hl_bytes", "ggd_decoder_packed_t_hl_bytes", "ggd_decoder_dzbuf_hl_bytes", "ggd_decoder_pack_hl", "ggd_decoder_forward_hl", "ggd_decoder_backward_wgrad_hl", "ggd_image_loss_tmp_bytes", "ggd_image_loss", "ggd_set_option", "ggd_get_option", "ggd_blend_stats", "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
 ]
 
 
@@ -100,7 +100,7 @@ def load():
         lib.ggd_decoder_backward_wgrad.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.ggd_decoder_packed_hl_bytes.restype = sz
         lib.ggd_decoder_packed_t_hl_bytes.restype = sz
-        lib.ggd_decoder_zbuf_hl_bytes.restype = sz; lib.ggd_decoder_zbuf_hl_bytes.argtypes = [i32]
+        lib.ggd_decoder_dzbuf_hl_bytes.restype = sz; lib.ggd_decoder_dzbuf_hl_bytes.argtypes = [i32]
         lib.ggd_decoder_pack_hl.argtypes = [vp, vp, C.POINTER(C.c_void_p), vp, vp]
         lib.ggd_decoder_forward_hl.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
         lib.ggd_decoder_backward_wgrad_hl.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -455,7 +455,7 @@ extern "C" int ggd_decoder_backward_wgrad(ggd_ctx* ctx, void* stream, int32_t N,
 
 // ---- the decoder at reference precision (split bf16 operands, csrc/ggd_mlp_hl.inc) -------------------------------------------
 extern "C" size_t ggd_decoder_packed_hl_bytes(void) { return (size_t)NHEAD * HLF_HEAD; }
-extern "C" size_t ggd_decoder_zbuf_hl_bytes(int32_t N) { return 2 * ggd_decoder_zbuf_bytes(N); }   // hi plane | lo plane
+extern "C" size_t ggd_decoder_dzbuf_hl_bytes(int32_t N) { return 2 * ggd_decoder_zbuf_bytes(N); }   // dz: hi plane | lo plane (z: one fp16 plane, ggd_decoder_zbuf_bytes)
 extern "C" size_t ggd_decoder_packed_t_hl_bytes(void) { return (size_t)NHEAD * HLT_HEAD; }
 
 extern "C" int ggd_decoder_pack_hl(ggd_ctx* ctx, void* stream, const float* const* params40, void* packed_hl,

@@ -183,8 +183,8 @@ class FusedDecoderFn(torch.autograd.Function):
         n = pos.shape[0]
         cx = _capi.context_for(dev)
         attrs = torch.empty((n, 16), dtype=torch.float32, device=dev)
-        planes = 2 if hl else 1     # reference precision: z kept as two bf16 planes (hi | lo)
-        zbuf = torch.empty((planes, 5, 3, (n + 15) // 16 * 16, HID), dtype=torch.bfloat16, device=dev)   # 16-point blocks (ggd_decoder_zbuf_bytes)
+        # 16-point blocks (ggd_decoder_zbuf_bytes); bf16 kernels: bf16 values, reference precision: fp16 values (opaque here)
+        zbuf = torch.empty((5, 3, (n + 15) // 16 * 16, HID), dtype=torch.bfloat16, device=dev)
         fwd = cx.lib.ggd_decoder_forward_hl if hl else cx.lib.ggd_decoder_forward_train
         with torch.cuda.device(dev):
             cx.check(fwd(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), C.c_void_p(feats.data_ptr()),
@@ -202,7 +202,8 @@ class FusedDecoderFn(torch.autograd.Function):
         n = pos.shape[0]
         dattrs = dattrs.contiguous().float()
         cx = _capi.context_for(dev)
-        dzbuf = torch.empty_like(zbuf)
+        # dz: one bf16 plane, or two (hi | lo) at reference precision
+        dzbuf = torch.empty(((2 if ctx.hl else 1),) + tuple(zbuf.shape), dtype=torch.bfloat16, device=dev)
         dout = torch.empty((5, n, 4), dtype=torch.float32, device=dev)
         dfeat = torch.empty((n, 32), dtype=torch.float32, device=dev)
         dinfo = torch.empty((n, 16), dtype=torch.float32, device=dev)

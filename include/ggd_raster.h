@@ -333,12 +333,12 @@ int ggd_decoder_backward_wgrad(ggd_ctx* ctx, void* stream, int32_t N, int32_t ch
  * every product evaluated as W_hi x_hi + W_hi x_lo + W_lo x_hi with fp32 accumulation (csrc/ggd_mlp_hl.inc), in the forward,
  * the backward and the weight gradients (outputs within 1e-5 of an fp32 evaluation).
  * The weight images have their own format (hi and lo image per layer): ggd_decoder_pack_hl builds both from the 40
- * parameter tensors (see ggd_decoder_pack).  zbuf and dzbuf hold TWO bf16 planes each (hi | lo, ggd_decoder_zbuf_hl_bytes(N) =
- * 2 x ggd_decoder_zbuf_bytes(N)); dout / dfeat / dinfo / wgrad as in the bf16 entry points (ggd_decoder_forward_hl with
- * zbuf == NULL is the inference form).
+ * parameter tensors (see ggd_decoder_pack).  zbuf: ggd_decoder_zbuf_bytes(N) as in the bf16 form, but holding fp16; dzbuf:
+ * TWO bf16 planes (hi | lo), ggd_decoder_dzbuf_hl_bytes(N) = 2 x ggd_decoder_zbuf_bytes(N); dout / dfeat / dinfo / wgrad as
+ * in the bf16 entry points (ggd_decoder_forward_hl with zbuf == NULL is the inference form).
  */
 size_t ggd_decoder_packed_hl_bytes(void);
-size_t ggd_decoder_zbuf_hl_bytes(int32_t N);
+size_t ggd_decoder_dzbuf_hl_bytes(int32_t N);
 size_t ggd_decoder_packed_t_hl_bytes(void);
 int ggd_decoder_pack_hl(ggd_ctx* ctx, void* stream, const float* const* params40, void* packed_hl, void* packed_t_hl);
 int ggd_decoder_forward_hl(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
