@@ -1,0 +1,15 @@
+#!/bin/bash
+# kernel times of the reference-precision decoder kernels for several builds of the library (timing experiments)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for v in "" _NOGELU _NOSTREAM _NOSTREAMDGGD_HL_NOBARRIER; do
+  if [ -n "$v" ]; then export GGD_LIB_PATH=$R/gaussian_gan_decoder_amd/libggd_raster$v.so; else unset GGD_LIB_PATH; fi
+  rm -rf /tmp/hv; rocprofv3 --kernel-trace --stats -d /tmp/hv -o p --output-format csv -- python $R/scripts/hl_only.py 3 > /tmp/hv.log 2>&1
+  echo "== variant '$v'"
+  python - <<'PY'
+import csv
+for r in csv.DictReader(open("/tmp/hv/p_kernel_stats.csv")):
+    if "hl_kernel" in r["Name"]:
+        print("   %-40s avg_us=%9.1f" % (r["Name"].split("(")[0][-40:], float(r["AverageNs"]) / 1e3))
+PY
+done
