@@ -18,5 +18,10 @@ for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     packed, packed_t = device_pack(dec, params, None, hl)
     a = FusedDecoderFn.apply(feats, pos, packed, packed_t, hl, *params)
     (a * w).sum().backward()
+# inference form (no z stores), same size
+from gaussian_gan_decoder_amd.fused_decoder import FusedDecoder
+inf = FusedDecoder(dec, precision="fp32" if hl else "bf16")
+for _ in range(3):
+    inf.decode_features(feats.detach(), pos)
 torch.cuda.synchronize()
 print("done")

@@ -9,7 +9,9 @@ for v in "" _NOGELU _NOSTREAM _NOSTREAMDGGD_HL_NOBARRIER; do
   python - <<'PY'
 import csv
 for r in csv.DictReader(open("/tmp/hv/p_kernel_stats.csv")):
-    if "hl_kernel" in r["Name"]:
-        print("   %-40s avg_us=%9.1f" % (r["Name"].split("(")[0][-40:], float(r["AverageNs"]) / 1e3))
+    n = r["Name"]
+    if "hl_kernel" in n:
+        tag = "backward" if "backward" in n else ("wgrad" if "wgrad" in n else ("pack" if "pack" in n else ("forward+z" if "ILb1E" in n or "<true>" in n else "forward")))
+        print("   %-12s avg_us=%9.1f" % (tag, float(r["AverageNs"]) / 1e3))
 PY
 done
