@@ -11,8 +11,8 @@
 // feature rows per lane group) IS a valid B-operand layout of the next layer, so activations never leave registers
 // between layers: no LDS round trip, no transposes.  (The MFMA pairs element e of lane (i,g) in A with element e
 // of lane (j,g) in B, so any assignment of k to (g,e) is legal as long as A and B agree; the weight rows are
-// pre-permuted on the host to the order the D layout produces.)  Weights of ONE head (<= 93 KiB bf16, rows padded by
-// 16 B so the 16-lane ds_read_b128 groups are bank-conflict free) are resident in LDS; a 512-thread workgroup
+// pre-permuted on the host to the order the D layout produces.)  Weights of ONE head (86 KiB bf16, 16-byte slots
+// XOR-swizzled by the row so that the ds_read_b128 lane groups are bank-conflict free) are resident in LDS; a 512-thread workgroup
 // (8 waves: two per SIMD, one in its MFMA phase while the other does its GELUs) walks 32-point slabs.
 // GELU is x * Phi(x) with a transcendental-free polynomial Phi (|GELU err| <= 2e-4 on [-4, 4], below bf16 resolution).
 #include "ggd_common.h"
@@ -26,14 +26,26 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int HID = 128;
 constexpr int NHEAD = 5;
 // LDS image of one head (bytes); rows are K bf16 + 8 bf16 of padding
-constexpr int ROW1 = (64 + 8) * 2;    // layer 1: K = 64 (32 plane features + 32 info slots)
-constexpr int ROW2 = (128 + 8) * 2;   // layers 2..4: K = 128
+// Weight rows are K bf16 with NO padding; the 16-byte slots of a row are XOR-swizzled by the row index so that a
+// ds_read_b128 of one k-slot of 16 consecutive rows by the four lane groups of a wave (rows i = lane & 15, slot g + 4 s) is
+// bank-conflict free: the LDS services a b128 read in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... over a
+// 256-byte bank row; with padded rows (stride 272 B) two lanes of every group met on one 16-byte slot (47 % of the LDS
+// cycles of these kernels were bank conflicts).  wslot() is the one place that knows the mapping; the pack kernels
+// (ggd_mlp_pack.inc, ggd_mlp_hl.inc) and fused_decoder.pack_weights write through the same formula.
+constexpr int ROW1 = 64 * 2;     // layer 1: K = 64 (32 plane features + 32 info slots): two rows per 256-byte bank row
+constexpr int ROW2 = 128 * 2;    // layers 2..4: K = 128: one row per bank row
+template <int ROW>
+__device__ __forceinline__ int wslot(int row, int q) {   // byte offset of logical 16-byte slot q of `row`
+  if (ROW == ROW2) return row * ROW2 + ((q ^ (row & 15)) << 4);
+  if (ROW == ROW1) return row * ROW1 + ((q ^ ((row >> 1) & 7)) << 4);
+  return row * ROW + (q << 4);                           // padded rows (W4^T): no swizzle
+}
 constexpr int OFF_W1 = 0;
 constexpr int OFF_W2 = OFF_W1 + HID * ROW1;
 constexpr int OFF_W3 = OFF_W2 + HID * ROW2;
 constexpr int OFF_W4 = OFF_W3 + HID * ROW2;
 constexpr int OFF_B = OFF_W4 + 16 * ROW2;          // fp32 biases: b1[128] b2[128] b3[128] b4[16]
-constexpr int HEAD_BYTES = OFF_B + (3 * HID + 16) * 4;  // 94,784 B
+constexpr int HEAD_BYTES = OFF_B + (3 * HID + 16) * 4;  // 87,616 B
 constexpr int MLP_THREADS = 512;
 constexpr int MLP_WAVES = MLP_THREADS / 64;
 // forward kernel: the waves that share one head's weights in LDS (95 KB: one workgroup per CU).  Measured at 1 M points:
@@ -106,17 +118,15 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* __restrict__ w, 
   bf16x8 a_cur[KB], a_nxt[KB];
   f4 b_cur, b_nxt;
   {
-    const unsigned char* row = w + (size_t)i * ROW + g * 16;
 #pragma unroll
-    for (int s = 0; s < KB; ++s) a_cur[s] = *reinterpret_cast<const bf16x8*>(row + s * 64);
+    for (int s = 0; s < KB; ++s) a_cur[s] = *reinterpret_cast<const bf16x8*>(w + wslot<ROW>(i, g + 4 * s));
     b_cur = *reinterpret_cast<const f4*>(bias + 4 * g);
   }
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     if (mt + 1 < 8) {
-      const unsigned char* row = w + (size_t)(16 * (mt + 1) + i) * ROW + g * 16;
 #pragma unroll
-      for (int s = 0; s < KB; ++s) a_nxt[s] = *reinterpret_cast<const bf16x8*>(row + s * 64);
+      for (int s = 0; s < KB; ++s) a_nxt[s] = *reinterpret_cast<const bf16x8*>(w + wslot<ROW>(16 * (mt + 1) + i, g + 4 * s));
       b_nxt = *reinterpret_cast<const f4*>(bias + 16 * (mt + 1) + 4 * g);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -257,10 +267,9 @@ __global__ __launch_bounds__(FWD_THREADS, FWD_WAVES / 4) void decoder_forward_ke
       {
         const f4 bb = *reinterpret_cast<const f4*>(b4 + 4 * g);
         out[0] = bb; out[1] = bb;
-        const unsigned char* row = wl + OFF_W4 + (size_t)j * ROW2 + g * 16;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(row + s * 64);
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(wl + OFF_W4 + wslot<ROW2>(j, g + 4 * s));
           out[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh[0][s], out[0], 0, 0, 0);
           out[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh[1][s], out[1], 0, 0, 0);
         }

@@ -16,7 +16,7 @@ from . import _capi
 from .decoder import SequentialDecoderReverse, triplane_mean
 
 HID = 128
-ROW1, ROW2 = 64 + 8, 128 + 8        # bf16 elements per padded weight row
+ROW1, ROW2 = 64, 128                # bf16 elements per weight row (no padding; 16-byte slots swizzled, see _swizzle_rows)
 # position (g, e) inside a 32-wide k block  <-  k = 4g+e (e < 4) or 16+4g+(e-4): the order the MFMA C/D layout
 # hands a layer's outputs to the next layer's B operand (csrc/ggd_mlp.hip header)
 _PERM32 = [(4 * g + e) if e < 4 else (16 + 4 * g + (e - 4)) for g in range(4) for e in range(8)]
@@ -48,9 +48,22 @@ def _check_decoder(decoder) -> None:
                          "(32 plane channels, 3-D positions)")
 
 
+def _swizzle_rows(wp: torch.Tensor) -> torch.Tensor:
+    """[rows, K] (K = 64 or 128) -> the same rows with their 8-element (16-byte) slots XOR-swizzled by the row index, the LDS
+    image the kernels read bank-conflict free (csrc/ggd_mlp.hip::wslot): physical slot = logical slot ^ (r & 15) for K = 128,
+    ^ ((r >> 1) & 7) for K = 64."""
+    rows, K = wp.shape
+    r = torch.arange(rows, device=wp.device)
+    sw = (r & 15) if K == 128 else ((r >> 1) & 7)
+    phys = torch.arange(K // 8, device=wp.device)[None, :] ^ sw[:, None]       # [rows, slots]: physical slot of logical slot q
+    out = torch.empty_like(wp).view(rows, K // 8, 8)
+    out.scatter_(1, phys[:, :, None].expand(rows, K // 8, 8), wp.view(rows, K // 8, 8))
+    return out.view(rows, K)
+
+
 def pack_weights(decoder: SequentialDecoderReverse) -> torch.Tensor:
-    """-> uint8 tensor of ggd_decoder_packed_bytes(): per head [W1 128x72 | W2 128x136 | W3 128x136 | W4 16x136] bf16,
-    then b1 b2 b3 [128] and b4 [16] fp32."""
+    """-> uint8 tensor of ggd_decoder_packed_bytes(): per head [W1 128x64 | W2 128x128 | W3 128x128 | W4 16x128] bf16 (slots
+    swizzled), then b1 b2 b3 [128] and b4 [16] fp32."""
     _check_decoder(decoder)
     dev = next(decoder.parameters()).device
     chunks = []
@@ -67,8 +80,8 @@ def pack_weights(decoder: SequentialDecoderReverse) -> torch.Tensor:
         b4[:l4.out_features] = l4.bias.detach().float()
         rows = []
         for w, row in ((w1, ROW1), (l2.weight.detach().float(), ROW2), (l3.weight.detach().float(), ROW2), (w4, ROW2)):
-            wp = torch.zeros(w.shape[0], row, device=dev)
-            wp[:, :w.shape[1]] = _permute_blocks(w)
+            assert row == w.shape[1]
+            wp = _swizzle_rows(_permute_blocks(w))
             rows.append(wp.to(torch.bfloat16).contiguous().view(torch.uint8).reshape(-1))
         biases = torch.cat([l1.bias.detach().float(), l2.bias.detach().float(), l3.bias.detach().float(), b4])
         chunks += rows + [biases.contiguous().view(torch.uint8).reshape(-1)]
@@ -96,8 +109,9 @@ def _head_tensors(decoder):
 
 
 def pack_weights_t(decoder: SequentialDecoderReverse) -> torch.Tensor:
-    """Transposed weight image for ggd_decoder_backward: per head [W4^T 128x40 | W3^T 128x136 | W2^T 128x136 |
-    W1^T 64x136] bf16, every row's K (= the layer's OUTPUT features) permuted like the forward image."""
+    """Transposed weight image for ggd_decoder_backward: per head [W4^T 128x40 | W3^T 128x128 | W2^T 128x128 |
+    W1^T 64x128] bf16, every row's K (= the layer's OUTPUT features) permuted like the forward image; the K = 128 rows
+    swizzled like the forward image, W4^T rows padded (32 + 8) and not swizzled."""
     dev = next(decoder.parameters()).device
     chunks = []
     for (w1, _, w2, _, w3, _, w4, _) in _head_tensors(decoder):
@@ -105,8 +119,11 @@ def pack_weights_t(decoder: SequentialDecoderReverse) -> torch.Tensor:
         w4f = torch.zeros(32, HID, device=dev); w4f[:w4.shape[0]] = w4.detach().float()
         for wt, row in ((w4f.t(), ROW4T), (w3.detach().float().t(), ROW2), (w2.detach().float().t(), ROW2),
                         (w1f.t(), ROW2)):
-            wp = torch.zeros(wt.shape[0], row, device=dev)
-            wp[:, :wt.shape[1]] = _permute_blocks(wt.contiguous())
+            if row == wt.shape[1]:
+                wp = _swizzle_rows(_permute_blocks(wt.contiguous()))
+            else:
+                wp = torch.zeros(wt.shape[0], row, device=dev)
+                wp[:, :wt.shape[1]] = _permute_blocks(wt.contiguous())
             chunks.append(wp.to(torch.bfloat16).contiguous().view(torch.uint8).reshape(-1))
     packed = torch.cat(chunks).contiguous()
     expect = _capi.load().ggd_decoder_packed_t_bytes()
