@@ -80,23 +80,9 @@ __device__ __forceinline__ f2v gelu2(f2v x) {
 // Four GELU pairs in lock step: the Horner recurrences of a packed polynomial are serial, and a v_pk_* op that reads the
 // result of the previous packed op needs a wait state (the compiler pads every step with s_nop 0: 800 of them per
 // slab and head) -- with four independent chains advanced together every dependent pair is four instructions apart
-// (904 -> 131 s_nop, 0.834 -> 0.806 ms at 1 M points).
+// (904 -> 131 s_nop, 0.834 -> 0.806 ms at 1 M points).  The same polynomial as eight independent plain-fp32 chains (no
+// v_pk_* at all) was measured too: 0.795 - 0.805 ms against 0.774 - 0.776 ms packed -- the packed form stays.
 __device__ __forceinline__ void gelu2x4(f2v (&x)[4]) {
-#ifdef GGD_GELU_SCALAR
-  // the same polynomial as eight independent plain-fp32 Horner chains (no v_pk_* ops): A/B switch, see DESIGN.md
-  float v[8] = {x[0].x, x[0].y, x[1].x, x[1].y, x[2].x, x[2].y, x[3].x, x[3].y}, xc[8], s2[8], p[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { xc[i] = __builtin_amdgcn_fmed3f(v[i], -4.0f, 4.0f); s2[i] = xc[i] * xc[i]; p[i] = -1.520480094e-09f; }
-  constexpr float CS[7] = {1.180964698e-07f, -4.014221549e-06f, 7.960997496e-05f, -1.041295812e-03f,
-                           9.641715482e-03f, -6.614117560e-02f, 3.988329117e-01f};
-#pragma unroll
-  for (int k = 0; k < 7; ++k)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) p[i] = __builtin_fmaf(p[i], s2[i], CS[k]);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = v[i] * __builtin_fmaf(xc[i], p[i], 0.5f);
-  x[0] = (f2v){v[0], v[1]}; x[1] = (f2v){v[2], v[3]}; x[2] = (f2v){v[4], v[5]}; x[3] = (f2v){v[6], v[7]};
-#else
   f2v xc[4], s2[4], p[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -113,7 +99,6 @@ __device__ __forceinline__ void gelu2x4(f2v (&x)[4]) {
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) x[i] = x[i] * __builtin_elementwise_fma(xc[i], p[i], (f2v){0.5f, 0.5f});
-#endif
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f4& lo, const f4& hi) {
