@@ -287,6 +287,31 @@ def main():
     stage_ms = {k: v / nprof for k, v in acc.items()}
     extra = {}
     ctx.set_profiling(False)
+    # ---- throughput with several frames in flight (reported BESIDE the single-stream headline, never instead of it): one HIP
+    #      stream + one rasterizer context per frame slot; frame k + 1's latency-bound preprocess / depth sort / binning
+    #      (about one workgroup per CU) runs under frame k's VALU-bound blend.  Images are bit-identical on every slot.
+    if rank == 0:
+        fif = {}
+        for nslots in (2, 4):
+            streams = [torch.cuda.Stream(device=dev) for _ in range(nslots)]
+            for st in streams:
+                st.wait_stream(torch.cuda.current_stream(dev))
+            outs = [None] * nslots
+            for i in range(4 * nslots):
+                with torch.cuda.stream(streams[i % nslots]):
+                    outs[i % nslots] = step()
+            torch.cuda.synchronize(dev)
+            nf = max(100, args.steps)
+            tf = time.perf_counter()
+            for i in range(nf):
+                with torch.cuda.stream(streams[i % nslots]):
+                    outs[i % nslots] = step()
+            torch.cuda.synchronize(dev)
+            tf = time.perf_counter() - tf
+            assert all(torch.equal(o[1], out[1]) for o in outs), "frames rendered on different streams differ"
+            fif[str(nslots)] = {"frames_per_s": nf / tf, "ms_per_frame": tf / nf * 1e3}
+            del streams, outs
+        extra["frames_in_flight"] = fif
     if not args.no_sweep and rank == 0:
         # the other synthetic configurations of BASELINE.json's north_star ({100k, 1M} x {512, 1024}), forward raster only,
         # 100 frames each -- reported for the table in DESIGN.md; the headline `value` is the workload above
