@@ -182,7 +182,9 @@ def test_capacity_hint_follows_scenes_of_varying_size(native_lib):
     dev = torch.device("cuda:0")
     P, S = 300_000, 512
     scenes = [scene_inputs(P=P, size=S, kind="shell", seed=40 + k, fov_deg=fov, lsm=-6.0) for k, fov in enumerate((5.0, 17.0, 8.0, 12.0))]
+    from _util import fragile_pixels
     oracles = [run_oracle(d) for d in scenes]
+    frags = [fragile_pixels(o) for o in oracles]      # pixels with a threshold decision an ulp of exp() flips
     Rs = [o["num_rendered"] for o in oracles]
     from gaussian_gan_decoder_amd.rasterizer import _capacity
     assert max(Rs) > 2 * min(Rs) and min(Rs) > 500_000, Rs             # 0.59 M .. 1.46 M instances
@@ -199,8 +201,8 @@ def test_capacity_hint_follows_scenes_of_varying_size(native_lib):
         assert n["num_rendered"] == o["num_rendered"]
         np.testing.assert_array_equal(n["point_list"], o["point_list"])
         np.testing.assert_array_equal(n["ranges"], o["ranges"])
-        same = n["n_contrib"] == o["n_contrib"]
-        assert (~same).sum() <= 1 and np.abs(n["color"].cpu().numpy() - o["color"])[:, same].max() <= RGB_ATOL
+        same = (n["n_contrib"] == o["n_contrib"]) | frags[k]
+        assert same.all() and np.abs(n["color"].cpu().numpy() - o["color"])[:, ~frags[k]].max() <= RGB_ATOL
     assert ctx.capacity_retries - retries_after_warmup <= 1, ctx.capacity_retries - retries_after_warmup
 
 
