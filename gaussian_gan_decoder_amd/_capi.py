@@ -129,6 +129,7 @@ class Context:
     def __init__(self, device_index: int):
         self.capacity_hint = {}
         self.capacity_retries = 0
+        self.poison_outputs = False   # tests: NaN-fill the backward's output arrays before the call
         self.lib = load()
         self.device_index = int(device_index)
         self.handle = self.lib.ggd_create(self.device_index)

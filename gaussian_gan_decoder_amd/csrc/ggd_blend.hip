@@ -4,18 +4,26 @@
 // gaussian_splatting/gaussian_renderer/__init__.py:167-175; algorithm restated in SURVEY.md 9.4 / 9.5).
 //
 // wave64 design (not the 16x16-thread block of the CUDA original):
-//   * A 64-lane wave owns a 16x16 tile (4 horizontally adjacent pixels per lane) or a 16x8 half of it (2 pixels per
-//     lane; template PXL) -- two waves per tile give finer culling, earlier exits and more waves per SIMD.  The pixels
-//     of a lane are handled as packed pairs (v_pk_*_f32: two pixels per VALU issue), a tile row is written as
-//     contiguous bytes, and the LDS cost of a record (3 broadcast reads) is amortised over all the lane's pixels.
-//   * The tile's sorted list is consumed 64 records per round: lane j gathers record j (one 48 B ggd_splat, three
-//     16 B loads; the next round's gather is in flight while the current one is blended), tests the record's
-//     alpha >= 1/255 box against the wave's pixel rectangle, and only the survivors are staged, compacted, in LDS.
-//   * Per staged record: a wave-level cull in the power domain before any exp, then a branch-free packed update.
-//   * No workgroup barrier, no __syncthreads_count: "wave finished" is one wave-uniform ballot.
-//   * Backward: the 9 per-Gaussian partial gradients are first summed over the lane's pixels, then over the wave
-//     with DPP row shifts (no LDS, no atomics), parked in LDS per staged record, and flushed with ONE global float
-//     atomic per (wave, Gaussian, component) instead of one per (pixel, Gaussian, component).
+//   * The unit of work is an 8x8 QUARTER of a 16x16 tile, one pixel per lane: forward = one single-wave workgroup per
+//     quarter (the four quarters of a tile in consecutive dispatch slots of one XCD, so that they share its L2); backward =
+//     four independent quarter waves (large grids) or four quarter waves in one workgroup that combine their per-record sums
+//     in LDS (small grids).  Wider blocks (16x8 with 2 pixels per lane, 16x16 with 4) are kept as options: the VALU cost of a
+//     blended record is proportional to the pixels a wave holds (packed fp32 brings no throughput on gfx950), while a
+//     record typically reaches less than half of a block, so the smallest block culls finest and idles fewest lanes.
+//   * A tile's depth-sorted list is consumed 64 records per round: lane j gathers record j (one 48-byte ggd_splat, three
+//     16-byte loads).  The gather is a two-stage software pipeline -- the list entries of round k + 2 and the records of
+//     round k + 1 are in flight while round k is blended.  The gathering lane tests its record against the wave's pixel
+//     rectangle (axis-aligned box of {alpha >= 1/255}, then the exact maximum of `power` over the rectangle); only the
+//     survivors are staged, compacted, in LDS, as loaded plus two in-place words.
+//   * Staged records are read back as LDS broadcasts in straight-line groups of 8.  Per record: a wave-level cull in the
+//     power domain before any exp (one scalar branch), then a branch-free update in which every per-pixel condition is a
+//     wave-uniform 64-bit lane mask in an SGPR pair (v_cmp -> SGPR, combined on the scalar unit) and every state change a VOP3
+//     select on such a mask with a tied destination (inline asm: the compiler's VCC-form select costs 8.7 issue slots).
+//   * No workgroup barrier in the forward or the quarter backward: "wave finished" is one wave-uniform ballot.
+//   * Backward: the 9 per-Gaussian partial gradients are reduced over the wave with a transposed DPP butterfly folded by the
+//     gfx950 lane-block swaps (no LDS round trip), parked in LDS per touched record, and flushed as (record, component) pairs
+//     over the lanes -- component fastest, so a record's nine float atomics form one 36-byte span -- instead of one atomic
+//     per (pixel, Gaussian, component).
 #include "ggd_common.h"
 
 namespace {

@@ -205,9 +205,6 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
     return int(R.value), color, radii, geom, binning, img
 
 
-POISON_OUTPUTS = False
-
-
 def rasterize_gaussians_backward_native(bg, means3D, radii, colors_precomp, scales, rotations, scale_modifier,
                                         cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, dL_dout_color, sh,
                                         degree, campos, geomBuffer, R, binningBuffer, imgBuffer, debug,
@@ -243,7 +240,7 @@ def rasterize_gaussians_backward_native(bg, means3D, radii, colors_precomp, scal
     dL_dsh = torch.empty((P, M, 3), **f32)
     dL_dscales = torch.empty((P, 3), **f32)
     dL_drotations = torch.empty((P, 4), **f32)
-    if POISON_OUTPUTS:   # tests: the library must write every element itself (it does not rely on pre-zeroed arrays)
+    if ctx.poison_outputs:   # tests: the library must write every element itself (it does not rely on pre-zeroed arrays)
         for t in (dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations):
             t.fill_(float("nan"))
     if P > 0:

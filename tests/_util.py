@@ -133,8 +133,9 @@ def decode_buffers(P, W, H, R, geom, binning, img):
 
 def run_native_backward(d, n, dL_dpix, device="cuda:0"):
     from gaussian_gan_decoder_amd import rasterizer as R
-    R.POISON_OUTPUTS = True   # NaN-fill the gradient arrays first: every element must be written by the library
     dev = torch.device(device)
+    from gaussian_gan_decoder_amd import _capi
+    _capi.context_for(dev).poison_outputs = True   # NaN-fill the gradient arrays first: every element must be written by the library
     t = lambda x: torch.empty(0, device=dev) if x is None else x.to(dev)
     outs = R.rasterize_gaussians_backward_native(
         t(d["bg"]), t(d["means3D"]), n["radii"], t(d["colors_precomp"]), t(d["scales"]), t(d["rotations"]),

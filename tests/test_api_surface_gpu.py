@@ -78,7 +78,8 @@ def test_render_through_the_shim_matches_oracle(native_lib, cov_py, sh_py):
     from gaussian_gan_decoder_amd.synthetic import make_camera, make_dL_dpix
     assert dgr.GaussianRasterizer is rasterizer.GaussianRasterizer
     assert dgr.GaussianRasterizationSettings is rasterizer.GaussianRasterizationSettings
-    rasterizer.POISON_OUTPUTS = True
+    from gaussian_gan_decoder_amd import _capi as _c
+    _c.context_for(torch.device("cuda:0")).poison_outputs = True
     dev = torch.device("cuda:0")
     S, P = 160, 6000
     d = scene_inputs(P=P, size=S, kind="cube", seed=11, sh_degree=1, sh_M=16, lsm=-5.0, h=1.0, v=1.3)
@@ -129,7 +130,7 @@ def test_render_through_the_shim_matches_oracle(native_lib, cov_py, sh_py):
     assert worst <= 1.0, worst
     for t in (pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._features_dc, pc._features_rest):
         assert t.grad is not None and torch.isfinite(t.grad).all()
-    rasterizer.POISON_OUTPUTS = False
+    _c.context_for(torch.device("cuda:0")).poison_outputs = False
 
 
 def test_non_fp32_inputs_are_refused(native_lib):
