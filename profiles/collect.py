@@ -23,10 +23,12 @@ def copy_stats(sub, out):
 
 copy_stats("bench", "kernel_stats.csv")
 copy_stats("train", "kernel_stats_train.csv")
+copy_stats("train_fp32", "kernel_stats_train_fp32.csv")
 for f in ("bench.json", "bench_under_rocprof.json", "full_size_errors.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
-for sub, out in (("pmc", "pmc_summary.txt"), ("pmc_shell", "pmc_summary_shell.txt"), ("pmc_mlp", "pmc_summary_mlp.txt")):
+for sub, out in (("pmc", "pmc_summary.txt"), ("pmc_shell", "pmc_summary_shell.txt"), ("pmc_mlp", "pmc_summary_mlp.txt"),
+                 ("pmc_hl", "pmc_summary_decoder_fp32.txt")):
     if os.path.isdir(os.path.join(src, sub)):
         txt = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "summarize_pmc2.py"), os.path.join(src, sub)],
                              capture_output=True, text=True).stdout
@@ -67,6 +69,7 @@ for sub, workload, out in (("pmc", "1M_1024_cube", "traffic.json"), ("pmc_shell"
                    "launches_per_frame": (len(dur[k]) / frames) if dur.get(k) else None}
     fwd = [k for k in kern if any(k.startswith(p) for p in ("preprocess_kernel", "scan_", "sort_", "rb_", "tilebin_", "duplicate_",
                                                             "ranges_", "blend_forward"))]
+    bwd_blend = next((k for k in kern if k.startswith("blend_backward")), "")
     doc = {"workload": workload,
            "source": f"profiles/{tag}/{'pmc_summary.txt' if sub == 'pmc' else 'pmc_summary_shell.txt'} (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
                      "averages per dispatch; scripts/pmc_passes.sh)",
@@ -75,7 +78,7 @@ for sub, workload, out in (("pmc", "1M_1024_cube", "traffic.json"), ("pmc_shell"
                          "and reports 1988, preprocess reads 54688 KiB and reports 27359); WRITE_SIZE unscaled",
            "kernels": kern,
            "forward_kernels": {k: kern[k]["launches_per_frame"] or 1 for k in fwd},
-           "stage_to_kernel": {"blend": next((k for k in kern if k.startswith("blend_forward")), ""),
+           "stage_to_kernel": {"blend": next((k for k in kern if k.startswith("blend_forward")), ""), "blend_bwd": bwd_blend,
                                "preprocess": "preprocess_kernel",
                                "duplicate": next((k for k in kern if k.startswith("rb_scatter2")), ""),
                                "sort": next((k for k in kern if k.startswith("sort_onesweep")), "")}}

@@ -6,8 +6,10 @@
 #   pmc/        counter passes (scripts/pmc_passes.sh) of the raster forward + backward, 1 M / 1024^2 cube
 #   pmc_shell/  ... of the shell scene
 #   pmc_mlp/    ... of the fused decoder MLP, inference kernel, 1 M points (incl. the MFMA counters)
+#   pmc_hl/     ... of the reference-precision decoder kernels (forward with z, backward, weight gradients), 2 M points
+#   train_fp32/ kernel trace of the train step with the reference-precision fused decoder
 set -u
-TAG=${1:-r02_final}
+TAG=${1:-r03_final}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
@@ -16,10 +18,13 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/bench -o p --output-forma
     > $R/gpurun_out/$TAG/bench_under_rocprof.json 2> $R/gpurun_out/$TAG/bench.err
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/train -o p --output-format csv -- \
     python $R/scripts/profile_train.py --fused > $R/gpurun_out/$TAG/train.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/train_fp32 -o p --output-format csv -- \
+    python $R/scripts/profile_train.py --fused --fp32 > $R/gpurun_out/$TAG/train_fp32.log 2>&1
 cd $R
 bash scripts/pmc_passes.sh $TAG/pmc scripts/fwd_only.py 1M_1024_cube 5 --backward > /dev/null
 bash scripts/pmc_passes.sh $TAG/pmc_shell scripts/fwd_only.py 1M_1024_shell 5 --backward > /dev/null
 bash scripts/pmc_passes.sh $TAG/pmc_mlp scripts/mlp_only.py 5 > /dev/null
+bash scripts/pmc_passes.sh $TAG/pmc_hl scripts/hl_only.py 3 > /dev/null
 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench_plain.err
 python -m pytest tests/test_full_size_gpu.py -m gpu -q -x -s 2>&1 | grep -E "max\||passed|failed|dRGB" > gpurun_out/$TAG/full_size_errors.txt
 echo done
