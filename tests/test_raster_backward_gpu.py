@@ -92,6 +92,32 @@ def test_backward_kernel_forms_match_oracle(native_lib, case, split):
         cx.set_option(_capi.OPT_BLEND_SPLIT, saved)
 
 
+@pytest.mark.parametrize("split", [3, 4])
+@pytest.mark.parametrize("cull", [0, 1])
+@pytest.mark.parametrize("exp_mode", [0, 1, 2])
+def test_backward_options_match_oracle(native_lib, split, cull, exp_mode):
+    """The backward blend's two production forms (tile form 3, quarter form 4) with wave-level culling on / off and the three
+    exp variants, each consistent with a forward run under the same options: all gradients inside the fp32 budget."""
+    import torch as _t
+    from gaussian_gan_decoder_amd import _capi
+    cx = _capi.context_for(_t.device("cuda:0"))
+    saved = [cx.get_option(o) for o in (_capi.OPT_BLEND_SPLIT, _capi.OPT_BLEND_CULL, _capi.OPT_EXP_MODE)]
+    try:
+        cx.set_option(_capi.OPT_BLEND_SPLIT, split); cx.set_option(_capi.OPT_BLEND_CULL, cull); cx.set_option(_capi.OPT_EXP_MODE, exp_mode)
+        d = scene_inputs(P=12000, size=160, kind="shell", lsm=-5.2, seed=17, width=160, height=112)
+        g = make_dL_dpix(160)[:, :112, :160].contiguous()
+        o = run_oracle(d)
+        n = run_native(d, debug=False)
+        ref, budget, fragile = backward_reference(d, o, n, g.numpy())
+        nb = run_native_backward(d, n, g)
+        report = []
+        worst = check_gradients(d, nb, ref, budget, fragile, report=report)
+        assert worst <= 1.0, (split, cull, exp_mode, report)
+    finally:
+        for o_, v in zip((_capi.OPT_BLEND_SPLIT, _capi.OPT_BLEND_CULL, _capi.OPT_EXP_MODE), saved):
+            cx.set_option(o_, v)
+
+
 def test_autograd_api_matches_oracle(native_lib):
     """Through GaussianRasterizer / render_simple exactly as the reference's train step does
     (main/train_pano2gaussian_decoder.py:223-232,263): activations in torch, grads on the RAW attributes.  Same

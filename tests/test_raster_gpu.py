@@ -124,7 +124,7 @@ def test_zero_negative_and_nan_opacity_never_contribute(native_lib):
     cx = _capi.context_for(torch.device("cuda:0"))
     saved = cx.get_option(_capi.OPT_BLEND_SPLIT)
     try:
-        for split in (1, 0, 2):
+        for split in (1, 0, 2, 3, 4):
             cx.set_option(_capi.OPT_BLEND_SPLIT, split)
             n = run_native(d, debug=False)
             np.testing.assert_array_equal(n["radii"].cpu().numpy(), o["radii"])
