@@ -184,6 +184,17 @@ __device__ __forceinline__ void fma_into(float& acc, float a, float b) {
 // Cost model (issue slots in units of one v_fma_f32, measured by the probe): plain VALU 1, packed fp32 1.85 (no
 // throughput gain over two plain ops on gfx950), v_cmp / VOP3 select / v_min 1.6, v_exp_f32 3.1: cull stage ~12 per
 // staged record, update ~55 per record that some pixel of the wave sees.
+// LDS reads through an explicit address-space-3 pointer (plain vector types: HIP's float4 class does not bind there)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const v4f lds_cf4;
+typedef __attribute__((address_space(3))) const v2f lds_cf2;
+__device__ __forceinline__ float4 lds_read4(lds_cf4* p) { const v4f v = *p; return make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ float2 lds_read2(lds_cf4* p, int word) {
+  const v2f v = *(lds_cf2*)((__attribute__((address_space(3))) const float*)p + word);
+  return make_float2(v[0], v[1]);
+}
+
 template <int EXP_MODE, bool CULL, int PXL, int BW, bool STATS>
 __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx, int T,
                                                            const ggd_splat* __restrict__ splat,
@@ -286,11 +297,16 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
     __syncthreads();
     for (int j0 = 0; j0 < n8; j0 += 8) {
       if (!wave_alive()) goto all_done;
-      const float4* grp = s_rec + j0 * 3;
+      // the group's LDS address, held in a VGPR the compiler cannot rematerialise: as a wave-uniform value it lives in an
+      // SGPR and every ds_read whose destination overlapped the address register re-copied it (two v_mov per record:
+      // 6 % of the issue slots of an update, 11 % of an in-loop cull)
+      uint32_t ga = (uint32_t)(uintptr_t)(lds_cf4*)(s_rec + j0 * 3);
+      asm volatile("" : "+v"(ga));
+      lds_cf4* grp = (lds_cf4*)(uintptr_t)ga;
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
-        const float4 a = grp[jj * 3 + 0];
-        const float2 b01 = *reinterpret_cast<const float2*>(grp + jj * 3 + 1);
+        const float4 a = lds_read4(grp + jj * 3 + 0);
+        const float2 b01 = lds_read2(grp + jj * 3 + 1, 0);
         const float dy = a.y - pyf;
         const float nBdy = a.w * dy, hCdy2 = (b01.x * dy) * dy;
         float pw[PXL];
@@ -309,8 +325,8 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
           for (int k = 0; k < PXL; ++k) { lanes |= need[k]; st_pixels += (uint32_t)__popcll(need[k]); }
           st_lanes += (uint32_t)__popcll(lanes);
         }
-        const float2 b23 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(grp + jj * 3 + 1) + 2);   // opacity, r
-        const float4 c = grp[jj * 3 + 2];                                                                             // g, b, contributor
+        const float2 b23 = lds_read2(grp + jj * 3 + 1, 2);                                                            // opacity, r
+        const float4 c = lds_read4(grp + jj * 3 + 2);                                                                 // g, b, contributor
         const uint32_t contributor = __float_as_uint(c.z);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
@@ -326,7 +342,7 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
           fma_into(C[k][2], c.y, w);
           sel_into_after(Tr[k], test_T, upd, w);
           sel_into(last[k], contributor, upd);
-          sel_into(px[k], INF, stop);
+          if (stop) sel_into(px[k], INF, stop);   // a pixel stops once: a scalar branch (SCC of the s_and above), not a select per update
         }
       }
     }

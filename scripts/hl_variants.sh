@@ -1,8 +1,9 @@
 #!/bin/bash
-# kernel times of the reference-precision decoder kernels for several builds of the library (timing experiments)
+# hl_variants.sh <suffix>...: kernel times of the reference-precision decoder kernels for the library and for the builds
+# gaussian_gan_decoder_amd/libggd_raster<suffix>.so (scripts/build_variant.sh) -- timing experiments
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for v in "" _NOGELU _NOSTREAM _NOSTREAMDGGD_HL_NOBARRIER; do
+for v in "" "$@"; do
   if [ -n "$v" ]; then export GGD_LIB_PATH=$R/gaussian_gan_decoder_amd/libggd_raster$v.so; else unset GGD_LIB_PATH; fi
   rm -rf /tmp/hv; rocprofv3 --kernel-trace --stats -d /tmp/hv -o p --output-format csv -- python $R/scripts/hl_only.py 3 > /tmp/hv.log 2>&1
   echo "== variant '$v'"
