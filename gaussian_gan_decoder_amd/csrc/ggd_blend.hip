@@ -234,6 +234,24 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
   const float wx0 = (float)(g.px0 - (lane % Geom::LPR) * PXL), wx1 = wx0 + (float)(BW - 1);
   const float wy0 = (float)(g.py - lane / Geom::LPR), wy1 = wy0 + (float)(Geom::BH - 1);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
+  // ... shrunk, round by round, to the bounding rectangle of the pixels that are still LIVE (8x8 one-pixel-per-lane form):
+  // a wave runs until its last pixel is finished, and towards the end most records reach the block but none of the few
+  // pixels left -- each such record cost a whole-wave test in the blend loop instead of one lane of the pre-cull.  Exact:
+  // a finished pixel ignores every record.
+  float lx0 = wx0, lx1 = wx1, ly0 = wy0, ly1 = wy1;
+  auto shrink_rect = [&]() {
+    if constexpr (PXL == 1 && BW == 8) {
+      const uint64_t live = __ballot(px[0] < INF);
+      if (live != 0ull) {
+        const int rmin = __builtin_ctzll(live) >> 3, rmax = (63 - __builtin_clzll(live)) >> 3;
+        uint32_t m = (uint32_t)live | (uint32_t)(live >> 32);
+        m |= m >> 16; m |= m >> 8; m &= 0xffu;
+        const int cmin = __builtin_ctz(m), cmax = 31 - __builtin_clz(m);
+        lx0 = wx0 + (float)cmin; lx1 = wx0 + (float)cmax;
+        ly0 = wy0 + (float)rmin; ly1 = wy0 + (float)rmax;
+      }
+    }
+  };
 
   // staged record = the 48-byte ggd_splat as loaded, two words replaced in place (three 16-byte LDS words, read back as
   // broadcasts; the cull stage needs the first two only):
@@ -261,8 +279,8 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
   auto consume = [&](uint32_t pos) {   // cull decision of the record in r0..r2, then its two in-place edits
     keep = false;
     if (pos < g.hi) {
-      keep = CULL ? (record_box_hits(r0.x, r0.y, r2.z, r2.w, wx0, wx1, wy0, wy1) &&
-                     record_reaches_block(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, wx0, wx1, wy0, wy1)) : true;
+      keep = CULL ? (record_box_hits(r0.x, r0.y, r2.z, r2.w, lx0, lx1, ly0, ly1) &&
+                     record_reaches_block(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, lx0, lx1, ly0, ly1)) : true;
       if (!CULL) r1.y = -__builtin_huge_valf();
       r2.z = __uint_as_float(pos - g.lo + 1u);
     }
@@ -272,6 +290,7 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
   load_rec(g.lo + lane);
   load_id(g.lo + 64 + lane);
   for (uint32_t base = g.lo; base < g.hi; base += 64) {
+    if (CULL) shrink_rect();
     consume(base + lane);          // the records requested one round ago
     __syncthreads();  // single-wave block: orders the previous round's LDS reads before this round's writes
     const uint64_t kept = __ballot(keep);
@@ -303,10 +322,18 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
       uint32_t ga = (uint32_t)(uintptr_t)(lds_cf4*)(s_rec + j0 * 3);
       asm volatile("" : "+v"(ga));
       lds_cf4* grp = (lds_cf4*)(uintptr_t)ga;
+      // the six words the cull test of a record needs are requested one record ahead (before the previous record's
+      // test and update), so that the test does not start with an LDS round trip
+      float4 a_nx = lds_read4(grp);
+      float2 b_nx = lds_read2(grp + 1, 0);
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
-        const float4 a = lds_read4(grp + jj * 3 + 0);
-        const float2 b01 = lds_read2(grp + jj * 3 + 1, 0);
+        const float4 a = a_nx;
+        const float2 b01 = b_nx;
+        if (jj < 7) {
+          a_nx = lds_read4(grp + (jj + 1) * 3);
+          b_nx = lds_read2(grp + (jj + 1) * 3 + 1, 0);
+        }
         const float dy = a.y - pyf;
         const float nBdy = a.w * dy, hCdy2 = (b01.x * dy) * dy;
         float pw[PXL];
