@@ -148,9 +148,13 @@ class Context:
 
     def blend_stats(self, enable: bool):
         """Start/stop the forward-blend work counters; returns the counters gathered since the last start."""
-        out = (C.c_ulonglong * 5)()
+        out = (C.c_ulonglong * 9)()
         self.check(self.lib.ggd_blend_stats(self.handle, int(bool(enable)), out))
-        return dict(zip(("visited", "culled", "lanes", "pixels", "listed"), [int(v) for v in out]))
+        d = dict(zip(("visited", "culled", "lanes", "pixels", "listed"), [int(v) for v in out[:5]]))
+        # residency of the blend waves in ticks of the 100 MHz constant clock (summed over the frames counted)
+        first = (~int(out[8])) & 0xFFFFFFFFFFFFFFFF
+        d.update(wave_ticks_sum=int(out[5]), wave_ticks_max=int(out[6]), span_ticks=(int(out[7]) - first) if out[7] else 0)
+        return d
 
     def set_profiling(self, on: bool):
         self.check(self.lib.ggd_set_profiling(self.handle, int(bool(on))))

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
   float INF = __builtin_huge_valf();
   asm volatile("" : "+v"(INF));   // keep it in a VGPR (VOP3 selects take no 32-bit literal)
   uint32_t st_visited = 0, st_culled = 0, st_lanes = 0, st_pixels = 0;  // wave-uniform debug counters (GGD stats)
+  const uint64_t st_t0 = STATS ? wall_clock64() : 0ull;                // 100 MHz constant clock: the wave's residency
   float Tr[PXL], C[PXL][3];   // per pixel: transmittance, accumulated colour
   uint32_t last[PXL];
   float px[PXL];              // pixel x coordinates; +inf once the pixel is finished / outside the image
@@ -382,6 +383,11 @@ all_done:
     atomicAdd(stats + 2, (unsigned long long)st_lanes);
     atomicAdd(stats + 3, (unsigned long long)st_pixels);
     atomicAdd(stats + 4, (unsigned long long)(g.hi - g.lo));
+    const uint64_t st_t1 = wall_clock64();
+    atomicAdd(stats + 5, (unsigned long long)(st_t1 - st_t0));   // sum of the waves' residency times
+    atomicMax(stats + 6, (unsigned long long)(st_t1 - st_t0));   // longest wave
+    atomicMax(stats + 7, (unsigned long long)st_t1);             // last end
+    atomicMax(stats + 8, (unsigned long long)~st_t0);            // ~(first start)
   }
   if (!row_in) return;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];

@@ -170,11 +170,11 @@ extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
 }
 extern "C" int ggd_blend_stats(ggd_ctx* ctx, int enable, unsigned long long* out) {
   if (!ctx) return GGD_E_INVALID;
-  unsigned long long* dev = reinterpret_cast<unsigned long long*>(ctx->d_words + 8);  // 5 x u64 inside the control block
+  unsigned long long* dev = reinterpret_cast<unsigned long long*>(ctx->d_words + 8);  // 9 x u64 inside the control block
   GGD_HIP(hipDeviceSynchronize());
-  if (out && ctx->blend_stats) GGD_HIP(hipMemcpy(out, dev, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (out && ctx->blend_stats) GGD_HIP(hipMemcpy(out, dev, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   if (enable) {
-    GGD_HIP(hipMemset(dev, 0, 5 * sizeof(unsigned long long)));
+    GGD_HIP(hipMemset(dev, 0, 9 * sizeof(unsigned long long)));
     ctx->blend_stats = dev;
   } else {
     ctx->blend_stats = nullptr;

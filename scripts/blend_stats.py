@@ -15,4 +15,7 @@ for (P, S, kind) in [(1000000, 1024, 'cube'), (1000000, 1024, 'shell'), (100000,
     st = ctx.blend_stats(False)
     v = max(st['visited'], 1); nc = max(v - st['culled'], 1)
     print(json.dumps(dict(P=P, S=S, kind=kind, **st, visited_frac=round(st['visited']/max(st['listed'],1), 3), culled_frac=round(st['culled']/v, 3),
-                          lanes_per_live_record=round(st['lanes']/nc, 1), pixels_per_live_record=round(st['pixels']/nc, 1))))
+                          lanes_per_live_record=round(st['lanes']/nc, 1), pixels_per_live_record=round(st['pixels']/nc, 1),
+                          span_us=st['span_ticks'] / 100.0, mean_wave_us=round(st['wave_ticks_sum'] / 100.0 / (4 * ((S + 15) // 16) ** 2), 2),
+                          longest_wave_us=st['wave_ticks_max'] / 100.0,
+                          mean_resident_waves_per_simd=round(st['wave_ticks_sum'] / max(st['span_ticks'], 1) / 1024, 2))))
