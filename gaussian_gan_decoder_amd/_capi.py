@@ -19,7 +19,7 @@ EXPORTS = [
     "ggd_img_layout", "ggd_sort_bits", "ggd_create", "ggd_destroy", "ggd_last_error", "ggd_version",
     "ggd_forward_geometry", "ggd_forward_render", "ggd_forward", "ggd_forward_can_speculate", "ggd_backward", "ggd_mark_visible", "ggd_debug_unsorted",
     "ggd_triplane_forward", "ggd_triplane_backward", "ggd_trigrid_forward", "ggd_trigrid_backward", "ggd_surface_tmp_bytes", "ggd_surface_sample", "ggd_decoder_packed_bytes", "ggd_decoder_pack", "ggd_decoder_forward", "ggd_decoder_zbuf_bytes", "ggd_decoder_packed_t_bytes",
-    "ggd_decoder_forward_train", "ggd_decoder_backward", "ggd_decoder_wgrad_floats", "ggd_decoder_wgrad", "ggd_decoder_backward_wgrad", "ggd_decoder_packed_hl_bytes", "ggd_decoder_packed_t_hl_bytes", "ggd_decoder_dzbuf_hl_bytes", "ggd_decoder_pack_hl", "ggd_decoder_forward_hl", "ggd_decoder_backward_wgrad_hl", "ggd_image_loss_tmp_bytes", "ggd_image_loss", "ggd_set_option", "ggd_get_option", "ggd_blend_stats", "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
+    "ggd_decoder_forward_train", "ggd_decoder_backward", "ggd_decoder_wgrad_floats", "ggd_decoder_wgrad", "ggd_decoder_backward_wgrad", "ggd_decoder_packed_hl_bytes", "ggd_decoder_packed_t_hl_bytes", "ggd_decoder_dzbuf_hl_bytes", "ggd_decoder_pack_hl", "ggd_decoder_forward_hl", "ggd_decoder_backward_wgrad_hl", "ggd_image_loss_tmp_bytes", "ggd_image_loss", "ggd_set_option", "ggd_get_option", "ggd_blend_stats", "ggd_blend_timeline", "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
 ]
 
 
@@ -109,6 +109,7 @@ def load():
         lib.ggd_set_option.argtypes = [vp, C.c_int, C.c_int]
         lib.ggd_get_option.argtypes = [vp, C.c_int]
         lib.ggd_blend_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_ulonglong)]
+        lib.ggd_blend_timeline.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
         lib.ggd_set_profiling.argtypes = [vp, C.c_int]
         lib.ggd_stage_name.restype = C.c_char_p; lib.ggd_stage_name.argtypes = [C.c_int]
         lib.ggd_stage_times.argtypes = [vp, C.POINTER(C.c_float)]
@@ -146,15 +147,21 @@ class Context:
     def get_option(self, option: int) -> int:
         return int(self.lib.ggd_get_option(self.handle, int(option)))
 
-    def blend_stats(self, enable: bool):
-        """Start/stop the forward-blend work counters; returns the counters gathered since the last start."""
-        out = (C.c_ulonglong * 9)()
-        self.check(self.lib.ggd_blend_stats(self.handle, int(bool(enable)), out))
-        d = dict(zip(("visited", "culled", "lanes", "pixels", "listed"), [int(v) for v in out[:5]]))
-        # residency of the blend waves in ticks of the 100 MHz constant clock (summed over the frames counted)
-        first = (~int(out[8])) & 0xFFFFFFFFFFFFFFFF
-        d.update(wave_ticks_sum=int(out[5]), wave_ticks_max=int(out[6]), span_ticks=(int(out[7]) - first) if out[7] else 0)
-        return d
+    def blend_stats(self, enable):
+        """Start (True / 1: work counters, 2: per-wave timeline) or stop (False) the forward-blend statistics; returns the
+        counters gathered since the last start."""
+        out = (C.c_ulonglong * 5)()
+        self.check(self.lib.ggd_blend_stats(self.handle, int(enable), out))
+        return dict(zip(("visited", "culled", "lanes", "pixels", "listed"), [int(v) for v in out]))
+
+    def blend_timeline(self, waves: int):
+        """[waves, 4] int64 array: start tick, end tick (100 MHz), list length, entries gathered -- of the forward blend that
+        ran after blend_stats(2)."""
+        import numpy as np
+        out = (C.c_ulonglong * (3 * waves))()
+        self.check(self.lib.ggd_blend_timeline(self.handle, out, int(waves)))
+        a = np.frombuffer(out, dtype=np.uint64).reshape(waves, 3)
+        return np.stack([a[:, 0], a[:, 1], a[:, 2] >> np.uint64(32), a[:, 2] & np.uint64(0xFFFFFFFF)], 1).astype(np.int64)
 
     def set_profiling(self, on: bool):
         self.check(self.lib.ggd_set_profiling(self.handle, int(bool(on))))

@@ -377,17 +377,17 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
   }
 all_done:
 
-  if (STATS && lane == 0) {
+  if (STATS && lane == 0 && stats[GGD_STATS_MODE] != 0ull) {
+    // timeline mode: this wave's [start, end] on the 100 MHz constant clock and the list entries it gathered -- plain
+    // stores to its own slot (the counters' same-address atomics stretch the kernel tenfold)
+    unsigned long long* slot = stats + GGD_STATS_HEAD + 3ull * blockIdx.x;
+    slot[0] = st_t0; slot[1] = wall_clock64(); slot[2] = ((unsigned long long)(g.hi - g.lo) << 32) | st_visited;
+  } else if (STATS && lane == 0) {
     atomicAdd(stats + 0, (unsigned long long)st_visited);
     atomicAdd(stats + 1, (unsigned long long)st_culled);
     atomicAdd(stats + 2, (unsigned long long)st_lanes);
     atomicAdd(stats + 3, (unsigned long long)st_pixels);
     atomicAdd(stats + 4, (unsigned long long)(g.hi - g.lo));
-    const uint64_t st_t1 = wall_clock64();
-    atomicAdd(stats + 5, (unsigned long long)(st_t1 - st_t0));   // sum of the waves' residency times
-    atomicMax(stats + 6, (unsigned long long)(st_t1 - st_t0));   // longest wave
-    atomicMax(stats + 7, (unsigned long long)st_t1);             // last end
-    atomicMax(stats + 8, (unsigned long long)~st_t0);            // ~(first start)
   }
   if (!row_in) return;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];

@@ -151,6 +151,7 @@ extern "C" void ggd_destroy(ggd_ctx* ctx) {
   if (ctx->h_words) (void)hipHostFree(ctx->h_words);
   if (ctx->sortctl) (void)hipFree(ctx->sortctl);
   if (ctx->scan_sums) (void)hipFree(ctx->scan_sums);
+  if (ctx->stats_buf) (void)hipFree(ctx->stats_buf);
   if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);
   if (ctx->dbg_vals) (void)hipFree(ctx->dbg_vals);
   for (int i = 0; i < 2 * ST_COUNT; ++i)
@@ -170,15 +171,27 @@ extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
 }
 extern "C" int ggd_blend_stats(ggd_ctx* ctx, int enable, unsigned long long* out) {
   if (!ctx) return GGD_E_INVALID;
-  unsigned long long* dev = reinterpret_cast<unsigned long long*>(ctx->d_words + 8);  // 9 x u64 inside the control block
   GGD_HIP(hipDeviceSynchronize());
-  if (out && ctx->blend_stats) GGD_HIP(hipMemcpy(out, dev, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (out && ctx->blend_stats) GGD_HIP(hipMemcpy(out, ctx->stats_buf, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   if (enable) {
-    GGD_HIP(hipMemset(dev, 0, 9 * sizeof(unsigned long long)));
-    ctx->blend_stats = dev;
+    const size_t bytes = (GGD_STATS_HEAD + 3ull * GGD_STATS_MAX_WAVES) * sizeof(unsigned long long);
+    if (!ctx->stats_buf) GGD_HIP(hipMalloc((void**)&ctx->stats_buf, bytes));
+    GGD_HIP(hipMemset(ctx->stats_buf, 0, bytes));
+    if (enable == 2) {   // per-wave timeline instead of the counters
+      const unsigned long long one = 1ull;
+      GGD_HIP(hipMemcpy(ctx->stats_buf + GGD_STATS_MODE, &one, sizeof(one), hipMemcpyHostToDevice));
+    }
+    ctx->blend_stats = ctx->stats_buf;
   } else {
     ctx->blend_stats = nullptr;
   }
+  return GGD_OK;
+}
+extern "C" int ggd_blend_timeline(ggd_ctx* ctx, unsigned long long* out, int waves) {
+  if (!ctx || !out || waves < 0 || waves > GGD_STATS_MAX_WAVES) return GGD_E_INVALID;
+  if (!ctx->stats_buf) return ggd_fail(ctx, GGD_E_INVALID, "ggd_blend_timeline: statistics were never enabled");
+  GGD_HIP(hipDeviceSynchronize());
+  GGD_HIP(hipMemcpy(out, ctx->stats_buf + GGD_STATS_HEAD, 3ull * waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return GGD_OK;
 }
 
@@ -464,7 +477,8 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
     }
     if (prm->debug) {
       if (ctx->dbg_cap < (size_t)R) {
-        if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);
+        if (ctx->stats_buf) (void)hipFree(ctx->stats_buf);
+  if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);
         if (ctx->dbg_vals) (void)hipFree(ctx->dbg_vals);
         ctx->dbg_keys = ctx->dbg_vals = nullptr; ctx->dbg_cap = 0;
         GGD_HIP(hipMalloc(&ctx->dbg_keys, (size_t)R * sizeof(uint64_t)));

@@ -23,6 +23,11 @@ enum {
 enum { GGD_ATTR_MLP_FWD = 1, GGD_ATTR_MLP_BWD = 2, GGD_ATTR_MLP_WGRAD = 4, GGD_ATTR_TILEBIN = 8, GGD_ATTR_TRIPLANE32 = 16,
        GGD_ATTR_TRIPLANE16 = 32, GGD_ATTR_MLP_HL = 64 };
 
+// layout of the debug statistics buffer of the forward blend (ggd_blend_stats / ggd_blend_timeline)
+constexpr int GGD_STATS_MODE = 9;            // word: 0 = counters (atomics), 1 = per-wave timeline slots
+constexpr int GGD_STATS_HEAD = 16;           // first timeline slot (3 words per wave: start, end, listed << 32 | gathered)
+constexpr int GGD_STATS_MAX_WAVES = 1 << 17;
+
 struct ggd_ctx {
   int device = 0;
   void* scratch = nullptr;      // grow-only device workspace (sort histograms, scan block sums, dL_dconic, ...)
@@ -43,6 +48,7 @@ struct ggd_ctx {
   size_t dbg_cap = 0;
   int opt[GGD_OPT_COUNT] = {2, 1, 1, 1};  // exp: compensated 2^x (1-ulp class like ocml expf, ~8 % faster blend)
   unsigned long long* blend_stats = nullptr;  // debug: device counters filled by the forward blend when non-null
+  unsigned long long* stats_buf = nullptr;    // its storage: [0..4] counters, [GGD_STATS_MODE] 1 = per-wave timeline, slots from GGD_STATS_HEAD
   bool profiling = false;
   hipEvent_t ev[2 * ST_COUNT] = {};
   bool ev_used[ST_COUNT] = {};

@@ -214,8 +214,13 @@ enum {
 int ggd_set_option(ggd_ctx* ctx, int option, int value);
 /* Debug: blend work counters of the NEXT forward calls: out[0]=records visited, [1]=records culled by the wave-level
  * test, [2]=lanes with a candidate pixel (summed over visited records), [3]=candidate pixels, [4]=sum of list lengths.
- * enable=1 starts (and zeroes) counting, enable=0 stops; out (host, 5 x uint64) may be NULL. */
+ * enable=1 starts (and zeroes) counting, enable=0 stops; out (host, 5 x uint64) may be NULL.
+ * enable=2 records, instead of the counters, a per-wave timeline of the next forward blend: ggd_blend_timeline copies, for
+ * the first `waves` workgroups of that launch, 3 x uint64 each: start and end on the device's 100 MHz constant clock, and
+ * (list length << 32 | list entries gathered before the wave's pixels were all finished).  (The counters are same-address
+ * atomics and stretch the kernel; the timeline is one plain store per wave.) */
 int ggd_blend_stats(ggd_ctx* ctx, int enable, unsigned long long* out);
+int ggd_blend_timeline(ggd_ctx* ctx, unsigned long long* out, int waves);
 int ggd_get_option(ggd_ctx* ctx, int option);
 
 /*
