@@ -38,3 +38,13 @@ for (P, S, kind) in [(1000000, 1024, 'cube'), (1000000, 1024, 'shell'), (100000,
                           longest_waves_start_us=[round(float(x), 1) for x in rel_start], longest_waves_us=[round(float(x), 1) for x in dur[longest]],
                           corr_duration_vs_entries_gathered=round(float(np.corrcoef(dur, tl[ok, 3])[0, 1]), 3),
                           visited_frac_mean=round(float(visited_frac.mean()), 3))))
+    if kind == 'cube' and S == 1024:
+        # coarse map (16 x 16 cells of 4 x 4 tiles): mean wave duration, mean start time; wave b -> tile as ggd_block_to_tile
+        b = np.arange(W); q = b >> 3; tile = (q // 4) * 8 + (b & 7); gx = S // 16
+        ty, tx = tile // gx, tile % gx
+        durs = np.zeros(W); durs[ok] = dur
+        starts = (t0 - t0[ok].min()) / 100.0
+        for name, val in (("duration_us", durs), ("start_us", starts), ("gathered", tl[:, 3].astype(float)), ("listed", tl[:, 2].astype(float))):
+            grid = np.zeros((16, 16)); cnt = np.zeros((16, 16))
+            np.add.at(grid, (ty // 4, tx // 4), val); np.add.at(cnt, (ty // 4, tx // 4), 1)
+            print(name); print(np.array2string(grid / cnt, precision=0, suppress_small=True, max_line_width=200))
