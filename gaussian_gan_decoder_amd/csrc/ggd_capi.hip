@@ -477,8 +477,7 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
     }
     if (prm->debug) {
       if (ctx->dbg_cap < (size_t)R) {
-        if (ctx->stats_buf) (void)hipFree(ctx->stats_buf);
-  if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);
+        if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);
         if (ctx->dbg_vals) (void)hipFree(ctx->dbg_vals);
         ctx->dbg_keys = ctx->dbg_vals = nullptr; ctx->dbg_cap = 0;
         GGD_HIP(hipMalloc(&ctx->dbg_keys, (size_t)R * sizeof(uint64_t)));

@@ -75,11 +75,17 @@ struct ggd_scan_piggy {
 int ggd_fail(ggd_ctx* ctx, int code, const std::string& msg);
 int ggd_reserve_scratch(ggd_ctx* ctx, size_t bytes, hipStream_t stream);
 
+static inline const char* ggd_basename(const char* p) {
+  const char* b = p;
+  for (; *p; ++p) if (*p == '/') b = p + 1;
+  return b;
+}
 #define GGD_HIP(call)                                                                                      \
   do {                                                                                                     \
     hipError_t e_ = (call);                                                                                \
     if (e_ != hipSuccess)                                                                                  \
-      return ggd_fail(ctx, GGD_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                \
+      return ggd_fail(ctx, GGD_E_HIP, std::string(#call) + " (" + ggd_basename(__FILE__) + ":" +            \
+                                          std::to_string(__LINE__) + "): " + hipGetErrorString(e_));         \
   } while (0)
 
 struct StageTimer {  // RAII hipEvent pair around one pipeline stage (no-op unless profiling is on)

@@ -209,3 +209,37 @@ def test_back_to_back_forwards_do_not_disturb_each_other(native_lib):
             assert torch.equal(color, c0)
             lst = binning.cpu().numpy()[:4 * Rn].view(np.uint32)       # the list sits at offset 0 of the binning buffer
             np.testing.assert_array_equal(lst, l0)
+
+
+def test_blend_statistics_do_not_change_the_image_and_account_for_every_wave(native_lib):
+    """The debug statistics of the forward blend (`ggd_blend_stats`, `ggd_blend_timeline`): the counted and the timed
+    instantiation of the kernel render the same image as the production one; the counters are consistent with the
+    frame (sum of list lengths = 4 quarter waves x num_rendered); the timeline has one slot per wave, every wave ends
+    after it starts and gathers no more than its list holds."""
+    from gaussian_gan_decoder_amd import rasterizer as R, _capi
+    dev = torch.device("cuda:0")
+    d = scene_inputs(P=20000, size=256, seed=5, lsm=-3.5)
+    t = lambda x: torch.empty(0, device=dev) if x is None else x.to(dev)
+    args = (t(d["bg"]), t(d["means3D"]), t(d["colors_precomp"]), t(d["opacities"]), t(d["scales"]), t(d["rotations"]),
+            d["scale_modifier"], t(d["cov3D_precomp"]), t(d["viewmatrix"]), t(d["projmatrix"]), d["tanfovx"], d["tanfovy"],
+            d["H"], d["W"], t(d["shs"]), d["sh_degree"], t(d["campos"]), False, False)
+    ctx = _capi.context_for(dev)
+    ref = R.rasterize_gaussians_native(*args)
+    torch.cuda.synchronize(dev)
+    try:
+        ctx.blend_stats(1)
+        counted = R.rasterize_gaussians_native(*args)
+        st = ctx.blend_stats(2)
+        timed = R.rasterize_gaussians_native(*args)
+        waves = 4 * ((d["W"] + 15) // 16) * ((d["H"] + 15) // 16)
+        tl = ctx.blend_timeline(waves)
+    finally:
+        ctx.blend_stats(False)
+    assert torch.equal(counted[1], ref[1]) and torch.equal(timed[1], ref[1])
+    assert st["listed"] == 4 * ref[0]
+    assert 0 < st["visited"] <= st["listed"] and st["culled"] <= st["visited"]
+    assert tl.shape == (waves, 4)
+    assert (tl[:, 1] >= tl[:, 0]).all() and (tl[:, 0] > 0).all()
+    assert int(tl[:, 2].sum()) == 4 * ref[0]
+    assert (tl[:, 3] <= tl[:, 2]).all()
+    assert int(tl[:, 3].sum()) == st["visited"]
