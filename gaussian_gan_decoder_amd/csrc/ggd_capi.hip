@@ -255,6 +255,7 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
                             const float* shs, const float* colors_precomp, const float* opacities,
                             const float* scales, const float* rotations, const float* cov3D_precomp,
                             void* geom_buf, int32_t* radii, int64_t* num_rendered, bool defer_scan = false) {
+  (void)hipGetLastError();   // a sticky error another library left in this thread is not ours to report
   int rc = check_params(ctx, prm);
   if (rc != GGD_OK) return rc;
   rc = check_inputs(ctx, prm, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp);
@@ -376,6 +377,7 @@ extern "C" int ggd_forward_geometry(ggd_ctx* ctx, void* stream, const ggd_params
 // the device); only the tile-binning path can run that way (its launch geometry does not depend on R).
 static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, const void* geom_buf, int64_t layout_R,
                           int64_t R, void* binning_buf, void* img_buf, float* out_color, bool speculative) {
+  (void)hipGetLastError();   // a sticky error another library left in this thread is not ours to report
   // layout_R: what binning_buf was laid out for; R: number of instances to process (== layout_R unless the caller
   // over-allocated; in the speculative case the true count is still on the device and R is only its upper bound)
   int rc = check_params(ctx, prm);
@@ -557,6 +559,7 @@ extern "C" int ggd_backward(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
                             const float* dL_dpix, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
                             float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
                             float* dL_drots) {
+  (void)hipGetLastError();   // a sticky error another library left in this thread is not ours to report
   int rc = check_params(ctx, prm);
   if (rc != GGD_OK) return rc;
   rc = check_inputs(ctx, prm, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp);
