@@ -408,7 +408,7 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
 
   const int bmode = ctx->opt[GGD_OPT_BINNING];
   // binning path: 0 = duplicate + radix sort; 2 = single-level tile binning; 3 = two-level row/column binning;
-  // 1 = auto: row binning when the grid is <= 64 x 64 tiles (and R is past its fixed costs), else as before
+  // 1 = auto: row binning when the grid is <= 255 x 255 tiles (and R is past its fixed costs), else as before
   const bool rowbin_ok = !prm->debug && ggd_rowbin_supported(prm->width, prm->height);
   const bool rowbin = rowbin_ok && (bmode == 3 || (bmode == 1 && R >= GGD_ROWBIN_MIN_R));
   const bool tilebin = rowbin || ((bmode == 2 || bmode == 3 || (bmode == 1 && R >= (1 << 20))) && !prm->debug &&
@@ -420,7 +420,7 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
     const uint32_t* depth_keys = reinterpret_cast<const uint32_t*>(gb + gv.depth_keys);
     const size_t pairs = ggd_align((size_t)prm->P * sizeof(uint32_t));
     const size_t sort_tmp = ggd_sort32_tmp_bytes(prm->P);
-    const size_t bin_tmp = rowbin ? ggd_rowbin_tmp_bytes(prm->P, capacity) : ggd_tilebin_tmp_bytes(prm->P, T);
+    const size_t bin_tmp = rowbin ? ggd_rowbin_tmp_bytes(prm->P, capacity, prm->width, prm->height) : ggd_tilebin_tmp_bytes(prm->P, T);
     rc = ggd_reserve_scratch(ctx, 4 * pairs + sort_tmp + bin_tmp, s);
     if (rc != GGD_OK) return rc;
     char* sc = static_cast<char*>(ctx->scratch);

@@ -140,7 +140,7 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
 const uint32_t* ggd_sort32_flat_ptr(const void* ctl);
 // Tile binning (GGD_OPT_BINNING = 1): sorted Gaussian order -> per-tile lists + ranges.
 bool ggd_rowbin_supported(int W, int H);
-size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity);
+size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity, int W, int H);
 int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect, const uint32_t* order,
                       const uint32_t* n_vis_ptr, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
                       size_t tmp_bytes, const uint32_t* order_alt = nullptr, const uint32_t* use_alt = nullptr,

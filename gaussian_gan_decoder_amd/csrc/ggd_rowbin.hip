@@ -1,4 +1,5 @@
-// ggd_rowbin.hip -- two-level stable tile binning for tile grids up to 64 x 64 (GGD_OPT_BINNING = 3 / auto).
+// ggd_rowbin.hip -- two-level stable tile binning (GGD_OPT_BINNING = 3 / auto): the kernels below for tile grids up to 64 x 64,
+// ggd_rowbin_wide.inc (same algorithm, bins spread over lane groups) for grids up to 255 x 255.
 //
 // Same contract as ggd_tilebin.hip (stages a6-a8 as a RESULT: per tile, the Gaussians whose rect covers it in
 // (depth bits, index) order, plus ranges), from the depth-ordered Gaussians.  The single-level pass there pays O(T) LDS
@@ -386,11 +387,23 @@ __global__ __launch_bounds__(RB_THREADS) void rb_scatter2_kernel(const uint2* __
 static inline int rb_blocks1(int P) { return (P + RB_CHUNK - 1) / RB_CHUNK; }
 static inline uint32_t rb_blocks2(uint32_t cap) { return (cap + RB_CHUNK - 1) / RB_CHUNK + 64; }
 
+#include "ggd_rowbin_wide.inc"
+
+static inline uint32_t rbw_blocks2(uint32_t cap) { return (cap + RB_CHUNK - 1) / RB_CHUNK + RBW_BINS; }
+static inline bool rb_is_wide(int W, int H) { return (W + 15) / 16 > 64 || (H + 15) / 16 > 64; }
+
 }  // namespace
 
-bool ggd_rowbin_supported(int W, int H) { return W > 0 && H > 0 && (W + 15) / 16 <= 64 && (H + 15) / 16 <= 64; }
+// grids up to 64 x 64 tiles: the lane-per-bin kernels above; up to 255 x 255: ggd_rowbin_wide.inc
+bool ggd_rowbin_supported(int W, int H) { return W > 0 && H > 0 && (W + 15) / 16 <= 255 && (H + 15) / 16 <= 255; }
 
-size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity) {
+size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity, int W, int H) {
+  if (rb_is_wide(W, H)) {
+    const int nby = 64 * (((H + 15) / 16 + 63) / 64), nbx = 64 * (((W + 15) / 16 + 63) / 64);
+    return ggd_align((size_t)P * sizeof(uint2)) + ggd_align((size_t)rb_blocks1(P) * nby * 4) +
+           ggd_align((size_t)RBW_TAB_WORDS * 4) + ggd_align((size_t)capacity * sizeof(uint2)) +
+           ggd_align((size_t)rbw_blocks2(capacity) * nbx * 4);
+  }
   return ggd_align((size_t)P * sizeof(uint2)) + ggd_align((size_t)rb_blocks1(P) * 64 * 4) +
          ggd_align((size_t)RB_TAB_WORDS * 4) + ggd_align((size_t)capacity * sizeof(uint2)) +
          ggd_align((size_t)rb_blocks2(capacity) * 64 * 4);
@@ -401,9 +414,30 @@ int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const 
                       const uint32_t* n_vis_ptr, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
                       size_t tmp_bytes, const uint32_t* order_alt, const uint32_t* use_alt, const ggd_scan_piggy* apply) {
   if (!ggd_rowbin_supported(prm.width, prm.height)) return ggd_fail(ctx, GGD_E_INVALID, "tile grid too large for row binning");
-  if (tmp_bytes < ggd_rowbin_tmp_bytes(prm.P, capacity)) return ggd_fail(ctx, GGD_E_INVALID, "rowbin tmp too small");
+  if (tmp_bytes < ggd_rowbin_tmp_bytes(prm.P, capacity, prm.width, prm.height)) return ggd_fail(ctx, GGD_E_INVALID, "rowbin tmp too small");
   const int gx = (prm.width + 15) / 16, gy = (prm.height + 15) / 16;
   char* p = static_cast<char*>(tmp);
+  if (rb_is_wide(prm.width, prm.height)) {
+    const int ngy = (gy + 63) / 64, ngx = (gx + 63) / 64, nby = 64 * ngy, nbx = 64 * ngx;
+    uint2* packed = reinterpret_cast<uint2*>(p); p += ggd_align((size_t)prm.P * sizeof(uint2));
+    uint32_t* counts1 = reinterpret_cast<uint32_t*>(p); p += ggd_align((size_t)rb_blocks1(prm.P) * nby * 4);
+    uint32_t* tab = reinterpret_cast<uint32_t*>(p); p += ggd_align((size_t)RBW_TAB_WORDS * 4);
+    uint2* ent = reinterpret_cast<uint2*>(p); p += ggd_align((size_t)capacity * sizeof(uint2));
+    uint32_t* counts2 = reinterpret_cast<uint32_t*>(p);
+    const int nb1 = rb_blocks1(prm.P);
+    const uint32_t nb2 = rbw_blocks2(capacity);
+    hipLaunchKernelGGL(rbw_count1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, rect, order, n_vis_ptr, prm.P, nby, packed,
+                       counts1, order_alt, use_alt);
+    hipLaunchKernelGGL(rbw_scan1_kernel, dim3(1), dim3(1024), 0, s, counts1, n_vis_ptr, prm.P, ngy, tab, capacity);
+    hipLaunchKernelGGL(rbw_scatter1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, packed, n_vis_ptr, prm.P, ngy, counts1, tab,
+                       ent, capacity);
+    hipLaunchKernelGGL(rbw_count2_kernel, dim3(nb2), dim3(RB_THREADS), 0, s, ent, capacity, tab, nbx, counts2);
+    hipLaunchKernelGGL(rbw_scan2_kernel, dim3(gy), dim3(1024), 0, s, counts2, tab, gx, gy, ngx, ranges);
+    hipLaunchKernelGGL(rbw_scatter2_kernel, dim3(nb2 + (apply ? (uint32_t)apply->nb : 0u)), dim3(RB_THREADS), 0, s, ent,
+                       capacity, tab, ngx, counts2, list, capacity, nb2, apply ? *apply : ggd_scan_piggy{});
+    GGD_HIP(hipGetLastError());
+    return GGD_OK;
+  }
   uint2* packed = reinterpret_cast<uint2*>(p); p += ggd_align((size_t)prm.P * sizeof(uint2));
   uint32_t* counts1 = reinterpret_cast<uint32_t*>(p); p += ggd_align((size_t)rb_blocks1(prm.P) * 64 * 4);
   uint32_t* tab = reinterpret_cast<uint32_t*>(p); p += ggd_align((size_t)RB_TAB_WORDS * 4);

@@ -201,8 +201,8 @@ enum {
                              0 = duplicateWithKeys + 64-bit (tile|depth) radix sort + identifyTileRanges,
                              2 = depth-sort the Gaussians once, then ONE stable tile-binning pass,
                              3 = depth-sort, then TWO 1-D stable binning passes (tile rows, then columns; grids up
-                                 to 64 x 64 tiles, falls back to 2 beyond),
-                             1 (default) = auto: 3 on grids up to 64 x 64 tiles; on larger grids 2 from 2^20 instances, else 0.
+                                 to 255 x 255 tiles = 4080 x 4080 pixels, falls back to 2 / 0 beyond),
+                             1 (default) = auto: 3 wherever it applies; beyond it 2 from 2^20 instances (<= 8192 tiles), else 0.
                              debug=1 (key taps) or a tile grid beyond the LDS budget always uses 0 */
   GGD_OPT_BLEND_SPLIT = 3, /* blend kernels: 0 = one wave per 16x16 tile (4 px/lane), 2 = two waves per tile (16x8
                              halves, 2 px/lane), 3 = four waves per tile (8x8 quarters, 1 px/lane; backward: the four in one

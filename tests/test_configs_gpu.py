@@ -1,8 +1,9 @@
 """GPU parity cases that close the configurations / code paths no other test reaches:
 
   * tile grids beyond 64 x 64 (stock 3DGS `render()` callers run at dataset resolution, gaussian_renderer/__init__.py:19-102;
-    the README quotes 1080p): 1920 x 1080 = 120 x 68 tiles (the single-level tile-binning path and the sort path) and
-    2048 x 2048 = 128 x 128 = 16 384 tiles (beyond the tile-binning path's limit: sort path only), every reachable
+    the README quotes 1080p): 1920 x 1080 = 120 x 68 tiles, 2048 x 2048 = 128 x 128 = 16 384 tiles (beyond the single-level
+    tile-binning path's limit), 3840 x 2160 = 240 x 135 and a 255-column strip (the row / column binning's last supported
+    width: ggd_rowbin_wide.inc takes every grid beyond 64 x 64 up to 255 x 255 tiles), every reachable
     binning option against the oracle -- lists / ranges exact, RGB <= 1e-5, all gradients inside their fp32 budget;
   * `prefiltered=True` with a culled point: upstream traps, the library returns GGD_E_PREFILTER -> RuntimeError, in both
     forms of the forward, and the context keeps working afterwards;
@@ -22,8 +23,9 @@ from gaussian_gan_decoder_amd.synthetic import make_dL_dpix
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("W,H,modes", [(1920, 1080, (0, 2, 3, None)), (2048, 2048, (0, 2, None)), (1040, 1040, (0, 2, 3, None))],
-                         ids=["1920x1080", "2048x2048", "1040x1040-65x65-tiles"])
+@pytest.mark.parametrize("W,H,modes", [(1920, 1080, (0, 2, 3, None)), (2048, 2048, (0, 2, 3, None)), (1040, 1040, (0, 2, 3, None)),
+                                       (3840, 2160, (3, None)), (4080, 1024, (3, 0))],
+                         ids=["1920x1080", "2048x2048", "1040x1040-65x65-tiles", "3840x2160", "4080x1024-255-tile-columns"])
 def test_large_tile_grids_match_oracle(native_lib, W, H, modes):
     P = 200_000
     d = scene_inputs(P=P, size=max(W, H), kind="cube", seed=4, lsm=-5.6, width=W, height=H)
