@@ -336,6 +336,26 @@ def main():
                            "tile_list_length": tile_list_stats(o2[5], S2, S2)}
             del sc2, a2, o2
         extra["forward_fps_other_workloads"] = sweep
+        # dataset-resolution frames (stock 3DGS render() callers; beyond the north_star's list): grids wider than 64 tiles
+        hd = {}
+        for name, (P2, W2, H2) in (("1M_1920x1080_cube", (1_000_000, 1920, 1080)), ("2M_3840x2160_cube", (2_000_000, 3840, 2160))):
+            sc2 = make_scene(P2, W2, "cube", seed=0).to(dev)
+            cam2 = sc2.cam
+            tx2 = math.tan(cam2.FoVx * 0.5)
+            a2 = (sc2.bg, sc2.xyz, empty, sc2.opacities.contiguous(), sc2.scales.contiguous(), sc2.rotations.contiguous(), 1.0,
+                  empty, cam2.world_view_transform, cam2.full_proj_transform, tx2, tx2 * H2 / W2, H2, W2,
+                  sc2.features_dc.contiguous(), 0, cam2.camera_center, False, False)
+            for _ in range(5):
+                o2 = R.rasterize_gaussians_native(*a2)
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            for _ in range(30):
+                o2 = R.rasterize_gaussians_native(*a2)
+            torch.cuda.synchronize(dev)
+            hd[name] = {"frames_per_s": 30.0 / (time.perf_counter() - t2), "num_rendered": int(o2[0]),
+                        "tiles": ((W2 + 15) // 16) * ((H2 + 15) // 16)}
+            del sc2, a2, o2
+        extra["forward_fps_dataset_resolution"] = hd
     if args.backward:
         ctx.set_profiling(True)
         g = make_dL_dpix(S).to(dev)
