@@ -14,7 +14,10 @@
 namespace {
 using namespace ggdm;
 
-__global__ __launch_bounds__(256) void preprocess_backward_kernel(
+// The per-Gaussian work of the kernels below.  dsh_stage: where this Gaussian's 3 M SH gradients go instead of
+// dL_dsh[i] (the staged kernel's LDS row), or nullptr.
+__device__ __forceinline__ void preprocess_backward_body(
+    int i, float* dsh_stage,
     int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int raw,
     const float* __restrict__ opacities_raw, float* __restrict__ dL_dopacity,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos_p,
@@ -24,8 +27,6 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     const float* __restrict__ grad_acc, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drots) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= P) return;
   const size_t ii = (size_t)i;
   if (radii[i] <= 0) {  // culled: every gradient of this Gaussian is zero (the caller does not pre-fill the arrays)
     dL_dmean2D[3 * ii] = 0.0f; dL_dmean2D[3 * ii + 1] = 0.0f; dL_dmean2D[3 * ii + 2] = 0.0f;
@@ -34,8 +35,10 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
     dL_dmeans3D[3 * ii] = 0.0f; dL_dmeans3D[3 * ii + 1] = 0.0f; dL_dmeans3D[3 * ii + 2] = 0.0f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) dL_dcov3D[6 * ii + k] = 0.0f;
-    if (!colors_precomp)
-      for (int k = 0; k < 3 * M; ++k) dL_dsh[ii * M * 3 + k] = 0.0f;
+    if (!colors_precomp) {
+      float* z = dsh_stage ? dsh_stage : dL_dsh + ii * M * 3;
+      for (int k = 0; k < 3 * M; ++k) z[k] = 0.0f;
+    }
     if (!cov3D_precomp) {
       dL_dscales[3 * ii] = 0.0f; dL_dscales[3 * ii + 1] = 0.0f; dL_dscales[3 * ii + 2] = 0.0f;
       reinterpret_cast<float4*>(dL_drots)[i] = make_float4(0, 0, 0, 0);
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
   // (3) colour -> SH coefficients (+ position through the view direction when deg > 0)
   if (!colors_precomp) {
     const float* sh = shs + ii * M * 3;
-    float* dsh = dL_dsh + ii * M * 3;
+    float* dsh = dsh_stage ? dsh_stage : dL_dsh + ii * M * 3;
     const uint32_t cl = clamped[i];
     const float v0 = p[0] - campos_p[0], v1 = p[1] - campos_p[1], v2 = p[2] - campos_p[2];
     const float len = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
@@ -265,6 +268,58 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(
   }
 }
 
+#define GGD_PPB_PARAMS                                                                                                  \
+    int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int raw,                              \
+    const float* __restrict__ opacities_raw, float* __restrict__ dL_dopacity, const float* __restrict__ view,           \
+    const float* __restrict__ proj, const float* __restrict__ campos_p, const float* __restrict__ means3D,              \
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp, const float* __restrict__ scales,          \
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const int32_t* __restrict__ radii,    \
+    const uint8_t* __restrict__ clamped, const float* __restrict__ grad_acc, float* __restrict__ dL_dmean2D,            \
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D,                     \
+    float* __restrict__ dL_dsh, float* __restrict__ dL_dscales, float* __restrict__ dL_drots
+#define GGD_PPB_ARGS                                                                                                    \
+    P, M, deg, W, H, tanfovx, tanfovy, mod, raw, opacities_raw, dL_dopacity, view, proj, campos_p, means3D, shs,        \
+    colors_precomp, scales, rotations, cov3D_precomp, radii, clamped, grad_acc, dL_dmean2D, dL_dcolors, dL_dmeans3D,    \
+    dL_dcov3D, dL_dsh, dL_dscales, dL_drots
+
+__global__ __launch_bounds__(256) void preprocess_backward_kernel(GGD_PPB_PARAMS) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  preprocess_backward_body(i, nullptr, GGD_PPB_ARGS);
+}
+
+// SH degree > 0 (M > 1 coefficients per channel): a Gaussian's 3 M gradients are 12 M bytes apart from its neighbour's, so
+// written by their owner lane they leave the wave as 3 M store instructions of 64 lone words each (1 M Gaussians, M = 16:
+// 494 us for this kernel against 88 us at M = 1).  Here every lane parks its row in LDS and the wave writes its 64 rows --
+// one contiguous 768 M-byte span of dL_dsh -- with lane-consecutive (16-byte where 3 M allows) stores.
+__global__ __launch_bounds__(256) void preprocess_backward_staged_kernel(GGD_PPB_PARAMS) {
+  extern __shared__ float s_dsh[];   // [256][3 M + 1]
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int rl = 3 * M, rowlen = rl + 1;
+  if (i < P) preprocess_backward_body(i, s_dsh + (size_t)threadIdx.x * rowlen, GGD_PPB_ARGS);
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  const int i0 = blockIdx.x * 256 + wv * 64;
+  const int nrows = min(64, P - i0);
+  if (nrows <= 0) return;
+  const float* rows = s_dsh + (size_t)wv * 64 * rowlen;
+  float* dst = dL_dsh + (size_t)i0 * rl;
+  const int total = nrows * rl;
+  if ((rl & 3) == 0) {
+    for (int e = 4 * lane; e < total; e += 256) {
+      const int r = e / rl, k = e - r * rl;
+      const float* src = rows + r * rowlen + k;
+      *reinterpret_cast<float4*>(dst + e) = make_float4(src[0], src[1], src[2], src[3]);
+    }
+  } else {
+    for (int e = lane; e < total; e += 64) {
+      const int r = e / rl, k = e - r * rl;
+      dst[e] = rows[r * rowlen + k];
+    }
+  }
+}
+
 }  // namespace
 
 int ggd_launch_preprocess_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const float* means3D,
@@ -275,6 +330,16 @@ int ggd_launch_preprocess_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params
                                    float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                                    float* dL_dscales, float* dL_drots) {
   if (prm.P == 0) return GGD_OK;
+  // the staged form whenever there is more than the band-0 coefficient per channel (and room: 256 rows of 3 M + 1 floats)
+  const bool staged = !colors_precomp && prm.M > 1 && (size_t)256 * (3 * prm.M + 1) * sizeof(float) <= 64 * 1024;
+  if (staged)
+    hipLaunchKernelGGL(preprocess_backward_staged_kernel, dim3((prm.P + 255) / 256), dim3(256),
+                       (size_t)256 * (3 * prm.M + 1) * sizeof(float), s, prm.P, prm.M,
+                       prm.sh_degree, prm.width, prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier,
+                       prm.raw_attributes, opacities, dL_dopacity, prm.viewmatrix, prm.projmatrix, prm.campos, means3D, shs, colors_precomp, scales, rotations,
+                       cov3D_precomp, radii, clamped, grad_acc, dL_dmean2D, dL_dcolors, dL_dmeans3D, dL_dcov3D,
+                       dL_dsh, dL_dscales, dL_drots);
+  else
   hipLaunchKernelGGL(preprocess_backward_kernel, dim3((prm.P + 255) / 256), dim3(256), 0, s, prm.P, prm.M,
                      prm.sh_degree, prm.width, prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier,
                      prm.raw_attributes, opacities, dL_dopacity, prm.viewmatrix, prm.projmatrix, prm.campos, means3D, shs, colors_precomp, scales, rotations,
