@@ -12,6 +12,10 @@
 namespace {
 using namespace ggdm;
 
+// SHVEC (more than the band-0 coefficient per channel, rows a multiple of 16 bytes: M = 4, 8, 12, 16): a visible Gaussian's
+// 3 M coefficients are fetched as 3 M / 4 dwordx4 loads into registers instead of 3 M lone words -- each such load
+// instruction touches 64 different rows whatever its width (1 M Gaussians, M = 16: preprocess 76 -> see DESIGN.md).
+template <bool SHVEC>
 __global__ __launch_bounds__(256) void preprocess_kernel(
     int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered, int raw,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos_p,
@@ -94,7 +98,20 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
           rgb[2] = colors_precomp[3 * (size_t)i + 2];
         } else {
           const float campos[3] = {campos_p[0], campos_p[1], campos_p[2]};
-          sh_to_rgb(deg, shs + (size_t)i * M * 3, p, campos, rgb, clamp_bits);
+          if constexpr (SHVEC) {
+            float shr[48];
+            const float4* src = reinterpret_cast<const float4*>(shs + (size_t)i * M * 3);
+            const int nq = (3 * M) >> 2;
+#pragma unroll
+            for (int qd = 0; qd < 12; ++qd) {
+              float4 v = make_float4(0, 0, 0, 0);
+              if (qd < nq) v = src[qd];
+              shr[4 * qd] = v.x; shr[4 * qd + 1] = v.y; shr[4 * qd + 2] = v.z; shr[4 * qd + 3] = v.w;
+            }
+            sh_to_rgb(deg, shr, p, campos, rgb, clamp_bits);
+          } else {
+            sh_to_rgb(deg, shs + (size_t)i * M * 3, p, campos, rgb, clamp_bits);
+          }
         }
         rect_out = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16), (uint32_t)miny | ((uint32_t)maxy << 16));
         const float conA = c * det_inv, conB = -b * det_inv, conC = a * det_inv;   // the published conic
@@ -167,11 +184,19 @@ int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, co
                           uint32_t* depth_keys, uint2* rect, uint32_t* trap_flag, uint32_t* zero_ptr, int zero_words) {
   if (prm.P == 0) return GGD_OK;
   const int grid = (prm.P + 255) / 256;
-  hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, s, prm.P, prm.M, prm.sh_degree, prm.width,
-                     prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.raw_attributes, prm.viewmatrix,
-                     prm.projmatrix, prm.campos, means3D, shs, colors_precomp, opacities, scales, rotations,
-                     cov3D_precomp, splat, tiles_touched, clamped, radii, depth_keys, rect, trap_flag, zero_ptr,
-                     zero_ptr ? zero_words : 0);
+  const bool shvec = !colors_precomp && prm.M > 1 && prm.M <= 16 && ((3 * prm.M) & 3) == 0;
+  if (shvec)
+    hipLaunchKernelGGL(preprocess_kernel<true>, dim3(grid), dim3(256), 0, s, prm.P, prm.M, prm.sh_degree, prm.width,
+                       prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.raw_attributes, prm.viewmatrix,
+                       prm.projmatrix, prm.campos, means3D, shs, colors_precomp, opacities, scales, rotations,
+                       cov3D_precomp, splat, tiles_touched, clamped, radii, depth_keys, rect, trap_flag, zero_ptr,
+                       zero_ptr ? zero_words : 0);
+  else
+    hipLaunchKernelGGL(preprocess_kernel<false>, dim3(grid), dim3(256), 0, s, prm.P, prm.M, prm.sh_degree, prm.width,
+                       prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.raw_attributes, prm.viewmatrix,
+                       prm.projmatrix, prm.campos, means3D, shs, colors_precomp, opacities, scales, rotations,
+                       cov3D_precomp, splat, tiles_touched, clamped, radii, depth_keys, rect, trap_flag, zero_ptr,
+                       zero_ptr ? zero_words : 0);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }
