@@ -356,6 +356,33 @@ def main():
                         "tiles": ((W2 + 15) // 16) * ((H2 + 15) // 16)}
             del sc2, a2, o2
         extra["forward_fps_dataset_resolution"] = hd
+        # a stock-3DGS-shaped optimisation step of the raster (what gaussian_renderer.render() + loss.backward() cost per
+        # iteration there): 1 M Gaussians, 1920 x 1080, SH degree 3 (16 coefficients per channel), forward + backward
+        sc2 = make_scene(1_000_000, 1920, "cube", seed=0).to(dev)
+        cam2 = sc2.cam
+        W2, H2 = 1920, 1080
+        tx2 = math.tan(cam2.FoVx * 0.5)
+        gsh = torch.Generator().manual_seed(3)
+        sh16 = torch.cat([sc2.features_dc, 0.05 * torch.randn(1_000_000, 15, 3, generator=gsh).to(dev)], 1).contiguous()
+        g2 = make_dL_dpix(1920).to(dev)[:, :H2, :W2].contiguous()
+        sc2s, sc2r = sc2.scales.contiguous(), sc2.rotations.contiguous()
+        fa = (sc2.bg, sc2.xyz, empty, sc2.opacities.contiguous(), sc2s, sc2r, 1.0, empty, cam2.world_view_transform,
+              cam2.full_proj_transform, tx2, tx2 * H2 / W2, H2, W2, sh16, 3, cam2.camera_center, False, False)
+
+        def fwd_bwd():
+            o = R.rasterize_gaussians_native(*fa)
+            R.rasterize_gaussians_backward_native(sc2.bg, sc2.xyz, o[2], empty, sc2s, sc2r, 1.0, empty, cam2.world_view_transform,
+                                                  cam2.full_proj_transform, tx2, tx2 * H2 / W2, g2, sh16, 3, cam2.camera_center,
+                                                  o[3], o[0], o[4], o[5], False)
+        for _ in range(3):
+            fwd_bwd()
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(20):
+            fwd_bwd()
+        torch.cuda.synchronize(dev)
+        extra["raster_fwd_bwd_1M_1080p_sh3"] = {"ms": (time.perf_counter() - t2) / 20 * 1e3}
+        del sc2, sh16, g2, fa
     if args.backward:
         ctx.set_profiling(True)
         g = make_dL_dpix(S).to(dev)
