@@ -982,12 +982,28 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
     const float4* p = reinterpret_cast<const float4*>(splat + id_nxt);
     r0 = p[0]; r1 = p[1]; r2 = p[2];
   };
+  // the pre-cull rectangle of a round = the bounding rectangle of the pixels that can see ANY record of the round (those
+  // whose last contributor lies at or behind the round's first position): walking back to front a wave starts at its
+  // deepest pixel, and until the others join, most records only reach pixels that are not live yet
+  float lx0 = wx0, lx1 = wx1, ly0 = wy0, ly1 = wy1;
+  auto shrink_rect = [&](uint32_t first_pos) {   // 0-based list position of the round's first record
+    const uint64_t live = __ballot(lastn > first_pos);
+    if (live != 0ull) {
+      const int rmin = __builtin_ctzll(live) >> 3, rmax = (63 - __builtin_clzll(live)) >> 3;
+      uint32_t m = (uint32_t)live | (uint32_t)(live >> 32);
+      m |= m >> 16; m |= m >> 8; m &= 0xffu;
+      const int cmin = __builtin_ctz(m), cmax = 31 - __builtin_clz(m);
+      lx0 = wx0 + (float)cmin; lx1 = wx0 + (float)cmax;
+      ly0 = wy0 + (float)rmin; ly1 = wy0 + (float)rmax;
+    }
+  };
   auto consume = [&](uint32_t ce) {
     keep = false;
     const uint32_t cs = round_start(ce);
+    if (CULL) shrink_rect(cs - rg.x);
     if ((uint32_t)lane < ce - cs) {
-      keep = CULL ? (record_box_hits(r0.x, r0.y, r2.z, r2.w, wx0, wx1, wy0, wy1) &&
-                     record_reaches_block(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, wx0, wx1, wy0, wy1)) : true;
+      keep = CULL ? (record_box_hits(r0.x, r0.y, r2.z, r2.w, lx0, lx1, ly0, ly1) &&
+                     record_reaches_block(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, lx0, lx1, ly0, ly1)) : true;
       if (!CULL) r1.y = -__builtin_huge_valf();
       r2.z = r1.w;
       r1.w = __uint_as_float((cs - rg.x) + (uint32_t)lane);
@@ -1035,10 +1051,14 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
     int cnt = 0;
     float* rows = &s_sum[0][0];
     for (int j0 = n8 - 8; j0 >= 0; j0 -= 8) {
-      const float4* grp = s_rec + j0 * 3;
+      uint32_t ga = (uint32_t)(uintptr_t)(lds_cf4*)(s_rec + j0 * 3);   // see blend_forward_kernel
+      asm volatile("" : "+v"(ga));
+      lds_cf4* grp = (lds_cf4*)(uintptr_t)ga;
+      float4 a_nx = lds_read4(grp + 7 * 3), b_nx = lds_read4(grp + 7 * 3 + 1);
 #pragma unroll
       for (int jj = 7; jj >= 0; --jj) {
-        const float4 a = grp[jj * 3 + 0], b = grp[jj * 3 + 1];
+        const float4 a = a_nx, b = b_nx;
+        if (jj > 0) { a_nx = lds_read4(grp + (jj - 1) * 3); b_nx = lds_read4(grp + (jj - 1) * 3 + 1); }
         const float dy = a.y - pyf;
         const float nBdy = a.w * dy, hCdy2 = (b.x * dy) * dy;
         const uint32_t pos0 = __float_as_uint(b.w);
@@ -1046,7 +1066,7 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
         const float pw = __builtin_fmaf(__builtin_fmaf(a.z, dx, nBdy), dx, hCdy2);
         const uint64_t need = __ballot(pos0 < lastn) & __ballot(pw >= b.y);
         if (need == 0ull) continue;
-        const float4 c = grp[jj * 3 + 2];                            // g, b, r, Gaussian id
+        const float4 c = lds_read4(grp + jj * 3 + 2);                // g, b, r, Gaussian id
         const float cA = -2.0f * a.z, cB = -a.w, cC = -2.0f * b.x;   // the conic (exact rescalings of hA, nB, hC)
         const float col[3] = {c.z, c.x, c.y};
         float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sop;                  // colour r g b | conic A B C | mean x y ; opacity
