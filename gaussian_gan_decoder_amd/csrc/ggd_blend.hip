@@ -14,7 +14,8 @@
 //     16-byte loads).  The gather is a two-stage software pipeline -- the list entries of round k + 2 and the records of
 //     round k + 1 are in flight while round k is blended.  The gathering lane tests its record against the wave's pixel
 //     rectangle (axis-aligned box of {alpha >= 1/255}, then the exact maximum of `power` over the rectangle); only the
-//     survivors are staged, compacted, in LDS, as loaded plus two in-place words.
+//     survivors are staged, compacted, in LDS, as loaded plus two in-place words.  The rectangle shrinks round by round
+//     to the pixels that are still live (forward) / that can see the round (backward).
 //   * Staged records are read back as LDS broadcasts in straight-line groups of 8.  Per record: a wave-level cull in the
 //     power domain before any exp (one scalar branch), then a branch-free update in which every per-pixel condition is a
 //     wave-uniform 64-bit lane mask in an SGPR pair (v_cmp -> SGPR, combined on the scalar unit) and every state change a VOP3
@@ -181,9 +182,11 @@ __device__ __forceinline__ void fma_into(float& acc, float a, float b) {
 //   (3) the exact per-pixel tests and the blend update, branch-free: every condition is a wave-uniform 64-bit lane mask
 //       (v_cmp -> SGPR pair, combined on the scalar unit), every state update one select on such a mask.
 // A finished pixel gets x = +inf: its power becomes -inf/NaN and it drops out in (2) with no extra instructions.
-// Cost model (issue slots in units of one v_fma_f32, measured by the probe): plain VALU 1, packed fp32 1.85 (no
-// throughput gain over two plain ops on gfx950), v_cmp / VOP3 select / v_min 1.6, v_exp_f32 3.1: cull stage ~12 per
-// staged record, update ~55 per record that some pixel of the wave sees.
+// Cost model (issue slots in units of one v_fma_f32 = ~2.5 cycles of a SIMD with >= 3 issuing waves, measured by the probes
+// under scripts/probes): plain VALU 1, packed fp32 1.85 (no throughput gain over two plain ops on gfx950), v_cmp / VOP3
+// select / v_min 1.6, v_exp_f32 3.1.  The forward executes 8 VALU instructions for a staged record no pixel sees and 28
+// for one some pixel sees; the kernel runs at ~0.85 of the VALU rate in its steady state and spends a third of its time
+// in ramp and tail.
 // LDS reads through an explicit address-space-3 pointer (plain vector types: HIP's float4 class does not bind there)
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
