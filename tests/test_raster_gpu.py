@@ -232,6 +232,41 @@ def test_row_binning_overflow_of_the_row_entries(native_lib):
     np.testing.assert_array_equal(n_big["ranges"], o_big["ranges"])
 
 
+@pytest.mark.parametrize("W,H", [(1280, 320), (320, 1280)], ids=["80x20-tiles", "20x80-tiles"])
+def test_wide_grid_row_binning_survives_capacity_overflow(native_lib, W, H):
+    """The same two overflows on grids beyond 64 tiles in one direction (ggd_rowbin_wide.inc: bins spread over lane
+    groups, columns resp. rows): the instance list and the row-entry list of a speculative forward are both too small
+    for the second scene; the retry must be exact, and the next call of the shape speculates successfully."""
+    from gaussian_gan_decoder_amd import _capi
+    from gaussian_gan_decoder_amd.rasterizer import _capacity
+    dev = torch.device("cuda:0")
+    P = 40000
+    small = scene_inputs(P=P, size=max(W, H), lsm=-7.5, seed=6, width=W, height=H)
+    big = scene_inputs(P=P, size=max(W, H), lsm=-3.0, seed=6, width=W, height=H)
+    ctx = _capi.context_for(dev)
+    for k in [k for k in ctx.capacity_hint if k[0] == P]:
+        ctx.capacity_hint.pop(k)
+    n_small = run_native(small, debug=False, binning=3)
+    o_small = run_oracle(small)
+    np.testing.assert_array_equal(n_small["point_list"], o_small["point_list"])
+    cap = _capacity(n_small["num_rendered"])
+    o_big = run_oracle(big)
+    assert o_big["num_rendered"] > 4 * cap
+    retries = ctx.capacity_retries
+    n_big = run_native(big, debug=False, binning=3)
+    assert ctx.capacity_retries == retries + 1
+    vis = o_big["radii"] > 0
+    r = n_big["rect"][vis]
+    assert (r[:, 3] - r[:, 1]).astype(np.int64).sum() > cap, "the row-entry list must overflow too"
+    assert n_big["num_rendered"] == o_big["num_rendered"]
+    np.testing.assert_array_equal(n_big["point_list"], o_big["point_list"])
+    np.testing.assert_array_equal(n_big["ranges"], o_big["ranges"])
+    n_big2 = run_native(big, debug=False, binning=3)
+    assert ctx.capacity_retries == retries + 1
+    np.testing.assert_array_equal(n_big2["point_list"], o_big["point_list"])
+    np.testing.assert_array_equal(n_big2["color"].cpu().numpy(), n_big["color"].cpu().numpy())
+
+
 def test_blend_options_do_not_change_the_image(native_lib):
     """Wave-level culling (GGD_OPT_BLEND_CULL) and the waves-per-tile split (GGD_OPT_BLEND_SPLIT) are exact
     optimisations: image, final_T and n_contrib are bit-identical with them on or off.  The exp variants
