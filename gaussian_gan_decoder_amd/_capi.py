@@ -184,6 +184,9 @@ class Context:
             pass
 
 
+# The reference's Python API has no context argument (`rasterize_gaussians(...)`, `GaussianRasterizer(settings)(...)`): the
+# library's contexts -- which hold ALL of its state: scratch, control words, options, capacity hints -- are created on
+# first use per (device, HIP stream) and looked up here.  The C library itself has no global state.
 _contexts: dict = {}
 
 

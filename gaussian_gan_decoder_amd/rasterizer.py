@@ -22,6 +22,7 @@ is no CPU path -- a CPU tensor raises.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from typing import NamedTuple, Optional
 
 import torch
@@ -63,20 +64,11 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if (t is None or t.numel() == 0) else C.c_void_p(t.data_ptr())
 
 
-_size_cache: dict = {}
-
-
+@functools.lru_cache(maxsize=4096)
 def _sizes(kind: str, a: int, b: int) -> int:
-    """ggd_geom_bytes(P) / ggd_img_bytes(W, H) / ggd_binning_bytes(R), memoised (pure functions of their arguments)."""
-    k = (kind, a, b)
-    v = _size_cache.get(k)
-    if v is None:
-        lib = _capi.load()
-        v = int(lib.ggd_geom_bytes(a) if kind == "g" else (lib.ggd_img_bytes(a, b) if kind == "i" else lib.ggd_binning_bytes(a)))
-        if len(_size_cache) > 4096:
-            _size_cache.clear()
-        _size_cache[k] = v
-    return v
+    """ggd_geom_bytes(P) / ggd_img_bytes(W, H) / ggd_binning_bytes(R): pure functions of their arguments, memoised."""
+    lib = _capi.load()
+    return int(lib.ggd_geom_bytes(a) if kind == "g" else (lib.ggd_img_bytes(a, b) if kind == "i" else lib.ggd_binning_bytes(a)))
 
 
 _HINT_DECAY = 0.98      # per frame: a one-off large frame is forgotten after ~100 frames (0.98^100 = 0.13)
