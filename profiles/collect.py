@@ -24,7 +24,8 @@ def copy_stats(sub, out):
 copy_stats("bench", "kernel_stats.csv")
 copy_stats("train", "kernel_stats_train.csv")
 copy_stats("train_fp32", "kernel_stats_train_fp32.csv")
-for f in ("bench.json", "bench_under_rocprof.json", "full_size_errors.txt"):
+copy_stats("hd", "kernel_stats_hd.csv")
+for f in ("bench.json", "bench_under_rocprof.json", "full_size_errors.txt", "hd_timing.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 for sub, out in (("pmc", "pmc_summary.txt"), ("pmc_shell", "pmc_summary_shell.txt"), ("pmc_mlp", "pmc_summary_mlp.txt"),

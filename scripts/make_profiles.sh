@@ -8,6 +8,7 @@
 #   pmc_mlp/    ... of the fused decoder MLP, inference kernel, 1 M points (incl. the MFMA counters)
 #   pmc_hl/     ... of the reference-precision decoder kernels (forward with z, backward, weight gradients), 2 M points
 #   train_fp32/ kernel trace of the train step with the reference-precision fused decoder
+#   hd/         kernel trace of scripts/hd_timing.py (1080p, 2048^2, 4K: every binning path that applies)
 set -u
 TAG=${1:-r03_final}
 R=$GRAFT_REPO_ROOT
@@ -20,6 +21,8 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/train -o p --output-forma
     python $R/scripts/profile_train.py --fused > $R/gpurun_out/$TAG/train.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/train_fp32 -o p --output-format csv -- \
     python $R/scripts/profile_train.py --fused --fp32 > $R/gpurun_out/$TAG/train_fp32.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/hd -o p --output-format csv -- \
+    python $R/scripts/hd_timing.py > $R/gpurun_out/$TAG/hd_timing.txt 2>&1
 cd $R
 bash scripts/pmc_passes.sh $TAG/pmc scripts/fwd_only.py 1M_1024_cube 5 --backward > /dev/null
 bash scripts/pmc_passes.sh $TAG/pmc_shell scripts/fwd_only.py 1M_1024_shell 5 --backward > /dev/null
