@@ -6,11 +6,14 @@ import torch
 from gaussian_gan_decoder_amd import rasterizer as R
 from gaussian_gan_decoder_amd.synthetic import make_scene
 dev = torch.device('cuda:0')
-def args_for(P, S, kind, seed):
+def args_for(P, S, kind, seed, H=None):
     sc = make_scene(P, S, kind, seed=seed).to(dev); cam = sc.cam; e = torch.empty(0, device=dev)
+    H = H or S
+    tx = math.tan(cam.FoVx*0.5)
     return (sc.bg, sc.xyz, e, sc.opacities.contiguous(), sc.scales.contiguous(), sc.rotations.contiguous(), 1.0, e, cam.world_view_transform,
-            cam.full_proj_transform, math.tan(cam.FoVx*0.5), math.tan(cam.FoVy*0.5), S, S, sc.features_dc.contiguous(), 0, cam.camera_center, False, False)
-scenes = [args_for(200000, 512, 'cube', 1), args_for(50000, 256, 'shell', 2), args_for(1000000, 1024, 'cube', 0), args_for(3000, 128, 'cube', 3)]
+            cam.full_proj_transform, tx, tx * H / S, H, S, sc.features_dc.contiguous(), 0, cam.camera_center, False, False)
+scenes = [args_for(200000, 512, 'cube', 1), args_for(50000, 256, 'shell', 2), args_for(1000000, 1024, 'cube', 0), args_for(3000, 128, 'cube', 3),
+          args_for(300000, 1920, 'cube', 4, H=1080), args_for(200000, 2048, 'shell', 5)]   # the last two: grids wider than 64 tiles
 ref = []
 for a in scenes:
     for _ in range(2): out = R.rasterize_gaussians_native(*a)
