@@ -225,7 +225,10 @@ __global__ __launch_bounds__(RS_THREADS) void sort_global_hist_kernel(const KeyT
 // pass takes its element count from *n_dev (= number of kept keys, written by the histogram kernel).  A later pass
 // whose digit is the same for all elements (ghist[d] == n: e.g. the exponent byte of a scene's depth range) degrades to
 // a tile copy: no ranking, no look-back.
-template <typename KeyT, bool IOTA, int ITEMS, bool COMPACT = false>
+// STAGE (large inputs): the tile's pairs are first put in digit order in LDS and copied out from there, so that the 16 or so
+// pairs a tile holds per digit leave as one run of lane-consecutive stores -- scattered straight from the registers every
+// pair is a lone 4-byte store, and from ~1 M kept keys on those partial-line writes, not the look-back, set a pass's time.
+template <typename KeyT, bool IOTA, int ITEMS, bool COMPACT = false, bool STAGE = false>
 __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
     const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, int64_t n_host, int shift, const uint32_t* __restrict__ ghist /*[256] of this pass*/,
@@ -241,6 +244,10 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
   __shared__ uint32_t s_scan[4];
   __shared__ uint32_t s_tile;
   __shared__ uint32_t s_flat;
+  __shared__ KeyT s_keys[STAGE ? RS_THREADS * ITEMS : 1];
+  __shared__ uint32_t s_vals[STAGE ? RS_THREADS * ITEMS : 1];
+  __shared__ uint32_t s_gdst[STAGE ? RS_BINS : 1];
+  __shared__ uint32_t s_ntile;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // A pass is a chain of dependent memory round trips (1-2 us each, one workgroup per CU, nothing to overlap them with):
   // everything that does not depend on anything else is requested up front -- the element count, this thread's bin
@@ -347,9 +354,39 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
     uint32_t tot;
     const uint32_t gbase = block_exclusive_scan_256(my_bin, &tot, s_scan);  // contains __syncthreads
     const uint32_t base = gbase + excl;
-    s_cnt[0][d] = base; s_cnt[1][d] = base + c0; s_cnt[2][d] = base + c0 + c1; s_cnt[3][d] = base + c0 + c1 + c2;
+    if constexpr (STAGE) {
+      uint32_t ltot;
+      const uint32_t lexcl = block_exclusive_scan_256(local, &ltot, s_scan);   // digit d's first slot inside the tile
+      s_cnt[0][d] = lexcl; s_cnt[1][d] = lexcl + c0; s_cnt[2][d] = lexcl + c0 + c1; s_cnt[3][d] = lexcl + c0 + c1 + c2;
+      s_gdst[d] = base - lexcl;          // slot p of the tile (digit d) goes to s_gdst[d] + p (mod 2^32)
+      if (d == 0) s_ntile = ltot;
+    } else {
+      s_cnt[0][d] = base; s_cnt[1][d] = base + c0; s_cnt[2][d] = base + c0 + c1; s_cnt[3][d] = base + c0 + c1 + c2;
+    }
   }
   __syncthreads();
+  if constexpr (STAGE) {
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+      const int64_t idx = wbase + r * 64 + lane;
+      if (idx < n && !(COMPACT && IOTA && key[r] == (KeyT)~(KeyT)0)) {
+        const uint32_t d = (uint32_t)(key[r] >> shift) & 0xffu;
+        const uint32_t p = s_cnt[wv][d] + rank[r];
+        s_keys[p] = key[r];
+        s_vals[p] = val[r];
+      }
+    }
+    __syncthreads();
+    const uint32_t nt = s_ntile;
+    for (uint32_t p = threadIdx.x; p < nt; p += RS_THREADS) {
+      const KeyT k = s_keys[p];
+      const uint32_t d = (uint32_t)(k >> shift) & 0xffu;
+      const size_t dst = (size_t)(uint32_t)(s_gdst[d] + p);
+      keys_out[dst] = k;
+      vals_out[dst] = s_vals[p];
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const int64_t idx = wbase + r * 64 + lane;
@@ -490,18 +527,31 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
   hipLaunchKernelGGL((sort_global_hist_kernel<uint32_t, RS32_ITEMS, true>), dim3(ntiles + pnb), dim3(RS_THREADS), 0, s,
                      keys_src, n, passes, ghist, n_valid, clean_ctl ? status : nullptr,
                      clean_ctl ? status_bytes / sizeof(uint32_t) : (size_t)0, ntiles, pg);
+  // the LDS-staged copy-out (measured, sort stage with / without: 1 M Gaussians 69.9 / 71.1 us, 5 M 201 / 235, 5 M shell
+  // 252 / 342, 10 M 340 / 390); GGD_SORT_STAGE_MIN_TILES=<tiles> restricts it to inputs of at least that many tiles
+  static const int stage_min = getenv("GGD_SORT_STAGE_MIN_TILES") ? atoi(getenv("GGD_SORT_STAGE_MIN_TILES")) : 0;
+  const bool stage = ntiles >= stage_min;
   // pass 0: keys_src (read-only, caller's buffer) -> B with identity values; then B -> A -> B -> A ...
   const uint32_t* kin = keys_src;
   const uint32_t* vin = nullptr;
   for (int p = 0; p < passes; ++p) {
     uint32_t* kout = (p & 1) ? keys_a : keys_b;
     uint32_t* vout = (p & 1) ? vals_a : vals_b;
-    if (p == 0)
+    if (p == 0 && !stage)
       hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, true, RS32_ITEMS, true>), dim3(ntiles + (pnb ? 1 : 0)),
                          dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 0, ghist, status, ntiles, gshift, tickets, n_valid,
                          2, pg);
-    if (p != 0)
+    if (p == 0 && stage)
+      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, true, RS32_ITEMS, true, true>), dim3(ntiles + (pnb ? 1 : 0)),
+                         dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 0, ghist, status, ntiles, gshift, tickets, n_valid,
+                         2, pg);
+    if (p != 0 && !stage)
       hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true>), dim3(ntiles + ((p == 1 && apply_here) ? pnb : 0)),
+                         dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 8 * p, ghist + p * RS_BINS,
+                         status + (size_t)p * pass_words, ntiles, gshift, tickets + p, n_valid, 3, pg,
+                         (flag_flat_last && p == passes - 1) ? tickets + RS_MAX_PASSES + 1 : nullptr);
+    if (p != 0 && stage)
+      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true, true>), dim3(ntiles + ((p == 1 && apply_here) ? pnb : 0)),
                          dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 8 * p, ghist + p * RS_BINS,
                          status + (size_t)p * pass_words, ntiles, gshift, tickets + p, n_valid, 3, pg,
                          (flag_flat_last && p == passes - 1) ? tickets + RS_MAX_PASSES + 1 : nullptr);
