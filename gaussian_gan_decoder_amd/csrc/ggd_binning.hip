@@ -527,30 +527,19 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
   hipLaunchKernelGGL((sort_global_hist_kernel<uint32_t, RS32_ITEMS, true>), dim3(ntiles + pnb), dim3(RS_THREADS), 0, s,
                      keys_src, n, passes, ghist, n_valid, clean_ctl ? status : nullptr,
                      clean_ctl ? status_bytes / sizeof(uint32_t) : (size_t)0, ntiles, pg);
-  // the LDS-staged copy-out (measured, sort stage with / without: 1 M Gaussians 69.9 / 71.1 us, 5 M 201 / 235, 5 M shell
-  // 252 / 342, 10 M 340 / 390); GGD_SORT_STAGE_MIN_TILES=<tiles> restricts it to inputs of at least that many tiles
-  static const int stage_min = getenv("GGD_SORT_STAGE_MIN_TILES") ? atoi(getenv("GGD_SORT_STAGE_MIN_TILES")) : 0;
-  const bool stage = ntiles >= stage_min;
+  // every pass copies its pairs out of LDS in digit order (STAGE; measured, sort stage with / without: 1 M Gaussians 69.9 /
+  // 71.1 us, 5 M 201 / 235, 5 M shell 252 / 342, 10 M 340 / 390)
   // pass 0: keys_src (read-only, caller's buffer) -> B with identity values; then B -> A -> B -> A ...
   const uint32_t* kin = keys_src;
   const uint32_t* vin = nullptr;
   for (int p = 0; p < passes; ++p) {
     uint32_t* kout = (p & 1) ? keys_a : keys_b;
     uint32_t* vout = (p & 1) ? vals_a : vals_b;
-    if (p == 0 && !stage)
-      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, true, RS32_ITEMS, true>), dim3(ntiles + (pnb ? 1 : 0)),
-                         dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 0, ghist, status, ntiles, gshift, tickets, n_valid,
-                         2, pg);
-    if (p == 0 && stage)
+    if (p == 0)
       hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, true, RS32_ITEMS, true, true>), dim3(ntiles + (pnb ? 1 : 0)),
                          dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 0, ghist, status, ntiles, gshift, tickets, n_valid,
                          2, pg);
-    if (p != 0 && !stage)
-      hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true>), dim3(ntiles + ((p == 1 && apply_here) ? pnb : 0)),
-                         dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 8 * p, ghist + p * RS_BINS,
-                         status + (size_t)p * pass_words, ntiles, gshift, tickets + p, n_valid, 3, pg,
-                         (flag_flat_last && p == passes - 1) ? tickets + RS_MAX_PASSES + 1 : nullptr);
-    if (p != 0 && stage)
+    if (p != 0)
       hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true, true>), dim3(ntiles + ((p == 1 && apply_here) ? pnb : 0)),
                          dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 8 * p, ghist + p * RS_BINS,
                          status + (size_t)p * pass_words, ntiles, gshift, tickets + p, n_valid, 3, pg,
