@@ -48,3 +48,15 @@ for (P, S, kind) in [(1000000, 1024, 'cube'), (1000000, 1024, 'shell'), (100000,
             grid = np.zeros((16, 16)); cnt = np.zeros((16, 16))
             np.add.at(grid, (ty // 4, tx // 4), val); np.add.at(cnt, (ty // 4, tx // 4), 1)
             print(name); print(np.array2string(grid / cnt, precision=0, suppress_small=True, max_line_width=200))
+    if kind == 'shell':
+        # how a wave's time grows with the rounds it walks, for the waves of the first dispatch round
+        first = ok & (t0 - t0[ok].min() < 500)
+        rounds = (tl[first, 3] + 63) // 64
+        d1 = (t1 - t0)[first] / 100.0
+        A = np.stack([np.ones(first.sum()), rounds.astype(float)], 1)
+        coef, *_ = np.linalg.lstsq(A, d1, rcond=None)
+        heavy = rounds >= 40
+        print(json.dumps(dict(first_round_waves=int(first.sum()), fit_us=dict(base=round(float(coef[0]), 1), per_round=round(float(coef[1]), 2)),
+                              waves_with_40_or_more_rounds=int(heavy.sum()),
+                              their_us_per_round=round(float((d1[heavy] / rounds[heavy]).mean()), 2) if heavy.any() else None,
+                              rounds_histogram=np.bincount(np.minimum(rounds // 10, 9).astype(int), minlength=10).tolist())))
