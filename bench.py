@@ -629,7 +629,7 @@ def main():
         result["train_fused_decoder_fp32"] = train_fused_fp32
     if extra:
         result["extra"] = extra
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed at N = 1 only (one rank, the whole host)
         result["cpu_baseline"] = cpu_baseline(P, S, kind)
     print(json.dumps(result), flush=True)
     if dist is not None:
