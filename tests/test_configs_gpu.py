@@ -74,6 +74,36 @@ def test_large_tile_grids_match_oracle(native_lib, W, H, modes):
     assert worst <= 1.0, f"gradient outside its fp32 error budget (worst ratio {worst:.2f})"
 
 
+def test_stock_3dgs_shaped_call_matches_oracle(native_lib):
+    """What a stock 3DGS optimisation step asks of the rasterizer: SH degree 3 (16 coefficients per channel: the dwordx4
+    register path of preprocess and its backward) on a 16:9 grid wider than 64 tiles (the row / column binning's group-wise
+    form), forward and backward against the oracle."""
+    W, H, P = 1280, 720, 60_000
+    d = scene_inputs(P=P, size=W, kind="cube", seed=9, sh_degree=3, lsm=-5.2, width=W, height=H)
+    o = run_oracle(d)
+    assert o["T"] == 80 * 45 and d["shs"].shape[1] == 16
+    frag = fragile_pixels(o)
+    g = make_dL_dpix(W)[:, :H, :W].contiguous()
+    g[:, torch.from_numpy(frag)] = 0.0
+    n = run_native(d, debug=False)
+    assert n["num_rendered"] == o["num_rendered"]
+    np.testing.assert_array_equal(n["point_list"], o["point_list"])
+    np.testing.assert_array_equal(n["ranges"], o["ranges"])
+    vis = o["radii"] > 0
+    np.testing.assert_array_equal(n["rgb"][vis], o["rgb"][vis])          # SH evaluation: bit-exact
+    oc = o["clamped"][vis].astype(np.uint8)
+    np.testing.assert_array_equal(n["clamped"][vis], oc[:, 0] | (oc[:, 1] << 1) | (oc[:, 2] << 2))   # one bit per channel
+    same = (n["n_contrib"] == o["n_contrib"]) | frag
+    assert same.all()
+    assert np.abs(n["color"].cpu().numpy() - o["color"])[:, ~frag].max() <= 1e-5
+    ref, budget, fragile = backward_reference(d, o, n, g.numpy())
+    nb = run_native_backward(d, n, g)
+    assert nb["dL_dsh"].shape == (P, 16, 3) and np.isfinite(nb["dL_dsh"]).all()
+    assert (nb["dL_dsh"][~vis] == 0).all()
+    worst = check_gradients(d, nb, ref, budget, fragile)
+    assert worst <= 1.0, f"gradient outside its fp32 error budget (worst ratio {worst:.2f})"
+
+
 def test_prefiltered_with_a_culled_point_raises(native_lib):
     """Upstream `prefiltered=True` promises that no point is culled by the frustum test and traps (__trap) otherwise;
     here: GGD_E_PREFILTER through the C ABI, RuntimeError in Python -- from the two-call form (first call of a shape) and from
