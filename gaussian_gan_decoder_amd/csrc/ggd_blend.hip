@@ -302,15 +302,12 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
       const int slot = __popcll(kept & lt_mask);
       s_rec[slot * 3 + 0] = r0; s_rec[slot * 3 + 1] = r1; s_rec[slot * 3 + 2] = r2;
     }
-    // the staged list is padded to a multiple of 8 with records no pixel can see (threshold +inf), so that a group of 8
-    // is straight-line code: LDS addresses are immediates, there is no loop counter, and a record that no pixel of the
-    // wave sees costs one scalar branch.  The blend state is updated in place by the tied-operand selects below, inside
-    // a wave-uniform `if` -- nothing is copied where the culled and the updated path join.
+    // the staged list is walked in groups of 8 of straight-line code: LDS addresses are immediates, there is no loop
+    // counter, a record that no pixel of the wave sees costs one scalar branch, and so does the end of the list inside the
+    // last group (padding that group with records nobody can see cost their cull tests: 1 % of the kernel).  The blend
+    // state is updated in place by the tied-operand selects below, inside a wave-uniform `if` -- nothing is copied where
+    // the culled and the updated path join.
     const int n = __popcll(kept), n8 = (n + 7) & ~7;
-    if (lane >= n && lane < n8) {
-      s_rec[lane * 3 + 0] = make_float4(0, 0, 0, 0);
-      s_rec[lane * 3 + 1] = make_float4(0, __builtin_huge_valf(), 0, 0);
-    }
     if (STATS) {
       st_visited += min(64u, g.hi - base);
       st_culled += min(64u, g.hi - base) - (uint32_t)__popcll(kept);
@@ -332,6 +329,7 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
       float2 b_nx = lds_read2(grp + 1, 0);
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
+        if (j0 + jj >= n) break;   // (scalar compare + branch: the last group of a round is usually not full)
         const float4 a = a_nx;
         const float2 b01 = b_nx;
         if (jj < 7) {
