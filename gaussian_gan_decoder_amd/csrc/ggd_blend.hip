@@ -91,7 +91,9 @@ __device__ __forceinline__ bool record_reaches_block(float x, float y, float hA,
   if (!(ex < __builtin_huge_valf())) return true;
   const float dx0 = x - wx1, dx1 = x - wx0, dy0 = y - wy1, dy1 = y - wy0;
   if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return true;
-  const float ihC = -0.5f / hC, ihA = -0.5f / hA;     // vertex of the edge parabolas: dy* = -nB X / (2 hC), dx* = -nB Y / (2 hA)
+  // vertex of the edge parabolas: dy* = -nB X / (2 hC), dx* = -nB Y / (2 hA).  (v_rcp_f32, 1 ulp: the correctly rounded
+  // divisions the build flags ask for cost two dozen instructions per record here, and the margin below dwarfs an ulp)
+  const float ihC = -0.5f * __builtin_amdgcn_rcpf(hC), ihA = -0.5f * __builtin_amdgcn_rcpf(hA);
   float pmax = -__builtin_huge_valf(), mag = 0.0f;
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
