@@ -82,7 +82,7 @@ __device__ __forceinline__ bool record_box_hits(float x, float y, float ex, floa
 // Second, exact stage of the pre-cull (same lane, only for records whose box hit): the largest `power` any point of the
 // wave's pixel rectangle can reach.  power(d) = hA dx^2 + nB dx dy + hC dy^2 (d = centre - pixel) is concave for a
 // positive-definite conic, so its maximum over the rectangle [dx0, dx1] x [dy0, dy1] is 0 if the rectangle contains the
-// centre and otherwise sits on one of the four edges, where it is a 1-D parabola maximised at the clamped vertex.  An
+// centre and otherwise sits on an edge facing the centre, where it is a 1-D parabola maximised at the clamped vertex.  An
 // elongated, tilted splat whose bounding box clips a block's corner is dropped here instead of costing every lane of
 // the wave a `power` evaluation.  Conservative: the test allows for the fp32 rounding of both evaluations (margin
 // proportional to the magnitude of the three terms); non-positive-definite conics (ex = +inf) are always kept.
@@ -94,20 +94,18 @@ __device__ __forceinline__ bool record_reaches_block(float x, float y, float hA,
   // vertex of the edge parabolas: dy* = -nB X / (2 hC), dx* = -nB Y / (2 hA).  (v_rcp_f32, 1 ulp: the correctly rounded
   // divisions the build flags ask for cost two dozen instructions per record here, and the margin below dwarfs an ulp)
   const float ihC = -0.5f * __builtin_amdgcn_rcpf(hC), ihA = -0.5f * __builtin_amdgcn_rcpf(hA);
-  float pmax = -__builtin_huge_valf(), mag = 0.0f;
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const float X = e ? dx1 : dx0;
-    const float dyv = fminf(fmaxf((nB * X) * ihC, dy0), dy1);
-    const float t1 = hA * X * X, t2 = nB * X * dyv, t3 = hC * dyv * dyv;
-    pmax = fmaxf(pmax, (t1 + t2) + t3);
-    mag = fmaxf(mag, (fabsf(t1) + fabsf(t2)) + fabsf(t3));
-    const float Y = e ? dy1 : dy0;
-    const float dxv = fminf(fmaxf((nB * Y) * ihA, dx0), dx1);
-    const float u1 = hA * dxv * dxv, u2 = nB * dxv * Y, u3 = hC * Y * Y;
-    pmax = fmaxf(pmax, (u1 + u2) + u3);
-    mag = fmaxf(mag, (fabsf(u1) + fabsf(u2)) + fabsf(u3));
-  }
+  // A concave function grows along every segment towards its maximiser (the centre, outside the rectangle here), so its
+  // maximum over the rectangle sits on an edge that FACES the centre: at most one edge per axis, the one nearer to it.
+  const bool in_x = dx0 <= 0.0f && dx1 >= 0.0f, in_y = dy0 <= 0.0f && dy1 >= 0.0f;
+  const float X = dx0 > 0.0f ? dx0 : dx1, Y = dy0 > 0.0f ? dy0 : dy1;
+  const float dyv = fminf(fmaxf((nB * X) * ihC, dy0), dy1);
+  const float t1 = hA * X * X, t2 = nB * X * dyv, t3 = hC * dyv * dyv;
+  const float px_ = (t1 + t2) + t3, mx_ = (fabsf(t1) + fabsf(t2)) + fabsf(t3);
+  const float dxv = fminf(fmaxf((nB * Y) * ihA, dx0), dx1);
+  const float u1 = hA * dxv * dxv, u2 = nB * dxv * Y, u3 = hC * Y * Y;
+  const float py_ = (u1 + u2) + u3, my_ = (fabsf(u1) + fabsf(u2)) + fabsf(u3);
+  const float pmax = in_x ? py_ : (in_y ? px_ : fmaxf(px_, py_));
+  const float mag = in_x ? my_ : (in_y ? mx_ : fmaxf(mx_, my_));
   return !(pmax < thr - (1e-3f + 1e-5f * mag));
 }
 
