@@ -44,95 +44,100 @@ def sample_from_planes(plane_features: torch.Tensor, coordinates: torch.Tensor, 
     inv = torch.linalg.inv(PLANE_AXES[plane_axes].to(coords.device, coords.dtype))   # [3,3,3]
     proj = torch.einsum("mc,pcd->pmd", coords, inv)                                    # [3, M, 3]
     if triplane_depth is None:
-        out = torch.nn.functional.grid_sample(plane_features, proj[..., :2].unsqueeze(1).float(), mode="bilinear",
+        out = torch.nn.functional.grid_sample(plane_features, proj[..., :2].unsqueeze(1).to(plane_features.dtype), mode="bilinear",
                                               padding_mode="zeros", align_corners=False)  # [3, C, 1, M]
         return out.permute(0, 3, 2, 1).reshape(n_planes, M, -1)
     D = int(triplane_depth)
     _, CD, H, W = plane_features.shape
     C = CD // D
     grid5 = plane_features.view(n_planes, C, D, H, W)
-    out = torch.nn.functional.grid_sample(grid5, proj.unsqueeze(1).unsqueeze(2).float(), mode="bilinear",
+    out = torch.nn.functional.grid_sample(grid5, proj.unsqueeze(1).unsqueeze(2).to(plane_features.dtype), mode="bilinear",
                                           padding_mode="zeros", align_corners=False)       # [3, C, 1, 1, M]
     return out.permute(0, 4, 3, 2, 1).reshape(n_planes, M, C)
 
 
-class _TrigridMeanFn(torch.autograd.Function):
-    """mean over the 3 planes of the tri-grid sample_from_planes, through the HIP gather kernel (csrc/ggd_triplane.hip,
-    ggd_trigrid_*): grids are handed over channel-last [3][D][H][W][C]."""
+def planes_channels_last(plane_features: torch.Tensor, triplane_depth=None) -> torch.Tensor:
+    """[3, C, H, W] -> [3, H, W, C] (EG3D tri-planes) or [3, C * D, H, W] -> [3, D, H, W, C] (PanoHead tri-grids, channel
+    index c * D + d as in PanoHead/training/volumetric_rendering/renderer.py:52): the layout the HIP gather kernels
+    read -- one texel's C channels are one contiguous line.  Plain differentiable torch ops (the permute back is
+    autograd's)."""
+    if triplane_depth is None:
+        return plane_features.permute(0, 2, 3, 1).contiguous().float()
+    n_planes, CD, H, W = plane_features.shape
+    D = int(triplane_depth)
+    return plane_features.view(n_planes, CD // D, D, H, W).permute(0, 2, 3, 4, 1).contiguous().float()
+
+
+class _PlanesGatherFn(torch.autograd.Function):
+    """mean over the 3 planes of sample_from_planes through the HIP kernels (csrc/ggd_triplane.hip: ggd_planes_gather /
+    ggd_planes_scatter).  planes_cl: channel-last [3, H, W, C] (depth 0) or [3, D, H, W, C]; coordinates [B, N, 3];
+    mod: None or per-scene modulations [B, max(D, 1), C] of the planes (scene b samples planes_cl * mod[b], never
+    materialised).  One autograd node for all B scenes: the backward ADDS every scene's scatter into ONE gradient buffer
+    (accumulate = 1) instead of B full-size gradients that autograd would sum pass by pass (a tri-grid of
+    3 x 96 x 256 x 256 is 75 MB)."""
 
     @staticmethod
-    def forward(ctx, plane_features, coordinates, box_warp, axes_mode, depth):
+    def forward(ctx, planes_cl, coordinates, mod, box_warp, axes_mode, depth):
         import ctypes as C
         from . import _capi
-        dev = plane_features.device
-        n_planes, CD, H, W = plane_features.shape
-        Cc = CD // depth
-        grids_cl = plane_features.view(n_planes, Cc, depth, H, W).permute(0, 2, 3, 4, 1).contiguous().float()
+        dev = planes_cl.device
+        if planes_cl.dtype != torch.float32 or not planes_cl.is_contiguous():
+            raise ValueError("planes_cl: contiguous float32 expected (planes_channels_last)")
+        Cc, H, W = planes_cl.shape[-1], planes_cl.shape[-3], planes_cl.shape[-2]
         pos = coordinates.contiguous().float()
-        out = torch.empty((pos.shape[0], Cc), dtype=torch.float32, device=dev)
+        B, n = pos.shape[0], pos.shape[1]
+        out = torch.empty((B * n, Cc), dtype=torch.float32, device=dev)
+        if mod is not None:
+            mod = mod.contiguous().float()
+            if mod.numel() != B * max(depth, 1) * Cc:
+                raise ValueError("mod: [B, max(D, 1), C] expected")
         cx = _capi.context_for(dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
-            cx.check(cx.lib.ggd_trigrid_forward(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
-                                                C.c_void_p(grids_cl.data_ptr()), Cc, depth, H, W, axes_mode,
-                                                C.c_void_p(pos.data_ptr()), pos.shape[0], float(box_warp),
-                                                C.c_void_p(out.data_ptr())))
-        ctx.save_for_backward(pos)
-        ctx.meta = (Cc, depth, H, W, float(box_warp), axes_mode)
+            for b in range(B):
+                cx.check(cx.lib.ggd_planes_gather(
+                    cx.handle, stream, C.c_void_p(planes_cl.data_ptr()), Cc, depth, H, W, axes_mode,
+                    C.c_void_p(mod[b].data_ptr()) if mod is not None else None, C.c_void_p(pos[b].data_ptr()), n,
+                    float(box_warp), C.c_void_p(out[b * n:].data_ptr())))
+        ctx.save_for_backward(pos, mod)
+        ctx.meta = (Cc, depth, H, W, float(box_warp), axes_mode, tuple(planes_cl.shape))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         import ctypes as C
         from . import _capi
-        (pos,) = ctx.saved_tensors
-        Cc, depth, H, W, box_warp, axes_mode = ctx.meta
+        pos, mod = ctx.saved_tensors
+        Cc, depth, H, W, box_warp, axes_mode, shape = ctx.meta
         dev = pos.device
+        B, n = pos.shape[0], pos.shape[1]
         dout = dout.contiguous().float()
-        dgrids_cl = torch.empty((3, depth, H, W, Cc), dtype=torch.float32, device=dev)
+        dplanes = torch.empty(shape, dtype=torch.float32, device=dev)
         cx = _capi.context_for(dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
-            cx.check(cx.lib.ggd_trigrid_backward(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), Cc, depth,
-                                                 H, W, axes_mode, C.c_void_p(pos.data_ptr()), pos.shape[0], box_warp,
-                                                 C.c_void_p(dout.data_ptr()), C.c_void_p(dgrids_cl.data_ptr())))
-        return dgrids_cl.permute(0, 4, 1, 2, 3).reshape(3, Cc * depth, H, W), None, None, None, None
+            for b in range(B):   # the first call zero-fills, the others add
+                cx.check(cx.lib.ggd_planes_scatter(
+                    cx.handle, stream, Cc, depth, H, W, axes_mode,
+                    C.c_void_p(mod[b].data_ptr()) if mod is not None else None, C.c_void_p(pos[b].data_ptr()), n, box_warp,
+                    C.c_void_p(dout[b * n:].data_ptr()), C.c_void_p(dplanes.data_ptr()), 0 if b == 0 else 1))
+        return dplanes, None, None, None, None, None
 
 
-class _TriplaneMeanFn(torch.autograd.Function):
-    """mean over the 3 planes of sample_from_planes, through the HIP gather kernel (csrc/ggd_triplane.hip)."""
-
-    @staticmethod
-    def forward(ctx, plane_features, coordinates, box_warp):
-        import ctypes as C
-        from . import _capi
-        dev = plane_features.device
-        n_planes, Cc, H, W = plane_features.shape
-        planes_cl = plane_features.permute(0, 2, 3, 1).contiguous().float()
-        pos = coordinates.contiguous().float()
-        out = torch.empty((pos.shape[0], Cc), dtype=torch.float32, device=dev)
-        cx = _capi.context_for(dev)
-        with torch.cuda.device(dev):
-            cx.check(cx.lib.ggd_triplane_forward(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
-                                                 C.c_void_p(planes_cl.data_ptr()), Cc, H, W, C.c_void_p(pos.data_ptr()),
-                                                 pos.shape[0], float(box_warp), C.c_void_p(out.data_ptr())))
-        ctx.save_for_backward(pos)
-        ctx.meta = (Cc, H, W, float(box_warp))
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        import ctypes as C
-        from . import _capi
-        (pos,) = ctx.saved_tensors
-        Cc, H, W, box_warp = ctx.meta
-        dev = pos.device
-        dout = dout.contiguous().float()
-        dplanes_cl = torch.empty((3, H, W, Cc), dtype=torch.float32, device=dev)
-        cx = _capi.context_for(dev)
-        with torch.cuda.device(dev):
-            cx.check(cx.lib.ggd_triplane_backward(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), Cc, H, W,
-                                                  C.c_void_p(pos.data_ptr()), pos.shape[0], box_warp,
-                                                  C.c_void_p(dout.data_ptr()), C.c_void_p(dplanes_cl.data_ptr())))
-        return dplanes_cl.permute(0, 3, 1, 2), None, None
+def planes_gather(planes_cl: torch.Tensor, coordinates: torch.Tensor, box_warp: float = 1.0, plane_axes: str = "eg3d",
+                  triplane_depth=None, mod=None) -> torch.Tensor:
+    """The HIP gather on channel-last planes (planes_channels_last): mean over the three planes of the bilinear /
+    trilinear sample of `planes_cl * mod`.  coordinates [M, 3] -> [M, C] (mod: [max(D, 1), C] or None), or a batch of
+    scenes sharing the planes: coordinates [B, N, 3], mod [B, max(D, 1), C] -> [B * N, C]."""
+    depth = 0 if triplane_depth is None else int(triplane_depth)
+    if depth == 0 and plane_axes != "eg3d":
+        raise ValueError("the 2-D tri-plane gather has the EG3D plane axes only")
+    if not planes_cl.is_cuda:
+        raise RuntimeError("planes_gather is a HIP kernel: CUDA tensors required (sample_from_planes is the torch form)")
+    if coordinates.dim() == 2:
+        coordinates = coordinates.unsqueeze(0)
+        mod = mod.unsqueeze(0) if mod is not None else None
+    return _PlanesGatherFn.apply(planes_cl, coordinates, mod, box_warp, {"eg3d": 0, "panohead": 1}[plane_axes], depth)
 
 
 def triplane_mean(plane_features: torch.Tensor, coordinates: torch.Tensor, box_warp: float = 1.0,
@@ -142,11 +147,9 @@ def triplane_mean(plane_features: torch.Tensor, coordinates: torch.Tensor, box_w
     PyTorch per the north_star, so a CPU path exists for tests -- unlike the rasterizer)."""
     C = plane_features.shape[1] // (1 if triplane_depth is None else int(triplane_depth))
     ok = plane_features.is_cuda and plane_features.shape[0] == 3 and C <= 64 and (C & (C - 1)) == 0
-    if ok and triplane_depth is None and plane_axes == "eg3d":
-        return _TriplaneMeanFn.apply(plane_features, coordinates, box_warp)
-    if ok and triplane_depth is not None:
-        return _TrigridMeanFn.apply(plane_features, coordinates, box_warp, {"eg3d": 0, "panohead": 1}[plane_axes],
-                                    int(triplane_depth))
+    if ok and (triplane_depth is not None or plane_axes == "eg3d"):
+        return planes_gather(planes_channels_last(plane_features, triplane_depth), coordinates, box_warp, plane_axes,
+                             triplane_depth)
     return sample_from_planes(plane_features, coordinates, box_warp, plane_axes, triplane_depth).mean(0)
 
 
@@ -247,9 +250,12 @@ class SequentialDecoderReverse(nn.Module):
     def activate_scale(self, scale):
         return -self.scale_activation(scale + 5) - 2.5
 
-    def forward(self, feature_planes, init_position):
+    def forward(self, feature_planes, init_position, features=None):
+        """features: the plane-mean features [N, C] when the caller has gathered them already (planes_gather on
+        channel-last planes: the training step); feature_planes is not read then."""
         # the 5 heads all average the three planes' samples
-        pf = triplane_mean(feature_planes, init_position, self.box_warp, self.plane_axes, self.triplane_depth)
+        pf = features if features is not None else \
+            triplane_mean(feature_planes, init_position, self.box_warp, self.plane_axes, self.triplane_depth)
         info = embed_positions(init_position) if self.use_xyz_embedding else init_position
         color = self.color_decoder(pf, info)
         info = torch.concat([info, color], dim=-1)

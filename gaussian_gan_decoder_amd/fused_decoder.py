@@ -309,20 +309,23 @@ class FusedTrainDecoder(torch.nn.Module):
         self._image_bufs = (packed, packed_t)
         return packed, packed_t
 
-    def forward_scenes(self, planes_list, positions):
+    def forward_scenes(self, planes_list, positions, feats=None):
         """Several scenes (own feature planes, positions[B,N,3]) through ONE decoder launch: attrs[B,N,16].  The
-        weight gradients are then formed once per step instead of once per scene."""
+        weight gradients are then formed once per step instead of once per scene.  feats [B * N, 32]: the plane-mean
+        features when the caller has gathered them already (decoder.planes_gather); planes_list is not read then."""
         B, N = positions.shape[0], positions.shape[1]
-        feats = torch.cat([triplane_mean(planes_list[b], positions[b], self.decoder.box_warp, self.decoder.plane_axes,
-                                         self.decoder.triplane_depth) for b in range(B)], dim=0)
+        if feats is None:
+            feats = torch.cat([triplane_mean(planes_list[b], positions[b], self.decoder.box_warp, self.decoder.plane_axes,
+                                             self.decoder.triplane_depth) for b in range(B)], dim=0)
         params = [t for head in _head_tensors(self.decoder) for t in head]
         packed, packed_t = self._images(params)
         a = FusedDecoderFn.apply(feats, positions.reshape(B * N, 3), packed, packed_t, self._hl, *params)
         return a.view(B, N, 16)
 
-    def forward(self, feature_planes, init_position):
-        feats = triplane_mean(feature_planes, init_position, self.decoder.box_warp, self.decoder.plane_axes,
-                              self.decoder.triplane_depth)
+    def forward(self, feature_planes, init_position, features=None):
+        feats = features if features is not None else \
+            triplane_mean(feature_planes, init_position, self.decoder.box_warp, self.decoder.plane_axes,
+                          self.decoder.triplane_depth)
         params = [t for head in _head_tensors(self.decoder) for t in head]
         packed, packed_t = self._images(params)
         a = FusedDecoderFn.apply(feats, init_position, packed, packed_t, self._hl, *params)

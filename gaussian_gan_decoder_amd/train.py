@@ -80,7 +80,14 @@ class DecoderTrainer:
                  l1_weight: float = 0.2, l2_weight: float = 0.1, ssim_weight: float = 0.5, sobel_weight: float = 0.2,
                  loss_fn=None, process_group=None, fused_activations: bool = False, fused_decoder: bool = False,
                  backbone_params: int = 0, perceptual_weight: float = 0.0, perceptual_width_div: int = 1,
-                 scene_streams: bool = False, decoder_precision: str = "bf16"):
+                 scene_streams: bool = False, decoder_precision: str = "bf16", plane_axes: str = "eg3d",
+                 triplane_depth=None, fused_planes=None):
+        """plane_axes / triplane_depth: the generator whose planes are decoded -- ("eg3d", None): tri-planes
+        [3, C, res, res]; ("panohead", 3): PanoHead's tri-grids [3, C * 3, res, res] sampled with a 3-D grid_sample
+        (the reference's default generator: main/train_pano2gaussian_decoder.py:43, PanoHead/train.py:230,318,
+        sequential_decoder_reverse.py:41-50).  fused_planes (default: on for CUDA): the scenes' planes
+        `planes * latent` are never materialised -- one channel-last copy of the shared planes per step, the per-scene
+        modulation applied inside the gather / scatter kernels, all scenes' plane gradients added into one buffer."""
         import torch.distributed as dist
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.pg = process_group
@@ -92,13 +99,18 @@ class DecoderTrainer:
         # CPU (gloo) tests inject the torch evaluation from tests/.
         self.loss_fn = loss_fn if loss_fn is not None else fused_image_loss
         torch.manual_seed(seed)
-        self.decoder = SequentialDecoderReverse(plane_channels, hidden_dim).to(self.device)
+        self.plane_axes, self.triplane_depth = plane_axes, (None if triplane_depth is None else int(triplane_depth))
+        depth = self.triplane_depth or 1
+        self.decoder = SequentialDecoderReverse(plane_channels, hidden_dim, plane_axes=plane_axes,
+                                                triplane_depth=self.triplane_depth).to(self.device)
         # stand-in for the finetuned GAN backbone (shared, replicated, all-reduced like the reference's G): ONE learnable
         # tri-plane, modulated per scene by a fixed per-scene channel code (the "latent" z of that scene)
         g = torch.Generator().manual_seed(seed + 17)
         self.planes = torch.nn.Parameter(
-            (0.5 * torch.randn(3, plane_channels, plane_res, plane_res, generator=g)).to(self.device))
-        self.latents = (1.0 + 0.25 * torch.randn(n_scenes_total, plane_channels, generator=g)).to(self.device)
+            (0.5 * torch.randn(3, plane_channels * depth, plane_res, plane_res, generator=g)).to(self.device))
+        self.latents = (1.0 + 0.25 * torch.randn(n_scenes_total, plane_channels * depth, generator=g)).to(self.device)
+        self.plane_channels = plane_channels
+        self.fused_planes = (self.device.type == "cuda") if fused_planes is None else bool(fused_planes)
         # the rest of the backbone's gradient payload (see the module docstring): a dense gradient every step through a
         # fixed probe vector, so that its all-reduce and Adam step do real work
         self.backbone = None
@@ -139,6 +151,8 @@ class DecoderTrainer:
         self.use_streams = bool(scene_streams) and self.device.type == "cuda"
         self._streams = []
         self.last_allreduce_bytes = 0
+        self.last_allreduce_bytes_in_backward = 0
+        self.measure_comm = False          # True: allreduce_and_step() brackets every unit's wait (allreduce_exposed_ms)
 
     # ---- gradients: one persistent flat buffer, bucketed --------------------------------------------------------------
     def _setup_flat_gradients(self, lr):
@@ -208,9 +222,34 @@ class DecoderTrainer:
         self._arm_units()
 
     def _arm_units(self):
+        """Ready for the next backward.  Collectives a failed step left in flight are waited for first (every rank
+        launched them in the same order, so they complete), never dropped: a stale handle would otherwise be waited on --
+        and a new collective skipped -- by the next step, and the ranks would diverge silently."""
         for u in self.units:
+            if u["work"] is not None:
+                u["work"].wait()
             u["missing"], u["work"] = u["need"], None
         self._launched_bytes = 0
+        self._launched_in_backward = 0
+        self._in_step_tail = False
+
+    def no_sync(self):
+        """Context manager for gradient accumulation: backward passes inside it add into the flat gradient without
+        launching any all-reduce; the backward that completes the accumulation runs outside it (its hooks launch the
+        units as usual), or allreduce_and_step() launches whatever is left."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            prev, self._defer = getattr(self, "_defer", False), True
+            try:
+                yield
+            finally:
+                self._defer = prev
+                for u in self.units:           # the next backward counts every parameter again
+                    if u["work"] is None:
+                        u["missing"] = u["need"]
+        return cm()
 
     def _launch_unit(self, u):
         u["work"] = self.dist.all_reduce(self.flat_grad[u["start"]:u["end"]], op=self.dist.ReduceOp.SUM, group=self.pg,
@@ -218,10 +257,17 @@ class DecoderTrainer:
         self._launched_bytes += (u["end"] - u["start"]) * 4
 
     def _grad_ready(self, p):
+        if getattr(self, "_defer", False):
+            return
         for u in self._units_of_param[id(p)]:
+            if u["work"] is not None or u["missing"] <= 0:
+                # a second backward would add into a slice whose all-reduce is already in flight (or done) and never be reduced
+                raise RuntimeError("DecoderTrainer: exactly one backward per allreduce_and_step() -- this parameter's "
+                                   "gradient was already handed to the all-reduce; accumulate under trainer.no_sync()")
             u["missing"] -= 1
-            if u["missing"] == 0 and u["work"] is None:
+            if u["missing"] == 0:
                 self._launch_unit(u)
+                self._launched_in_backward += (u["end"] - u["start"]) * 4
 
     def allreduce_and_step(self):
         """Per bucket: wait for its units' all-reduces (launched from the backward by the hooks; any unit a hook did not
@@ -233,30 +279,78 @@ class DecoderTrainer:
             for u in self.units:
                 if u["work"] is None:
                     self._launch_unit(u)
+        stalls = []
         for k, (s, e, _) in enumerate(self.buckets):
             g = self.flat_grad[s:e]
             if multi:
                 for u in self.units:
                     if u["bucket"] == k:
-                        u["work"].wait()
+                        if self.measure_comm:
+                            stalls.append(self._timed_wait(u["work"]))
+                        else:
+                            u["work"].wait()
                 g /= world
             # the reference sanitises on every step, single-GPU runs included (eg3d/training/training_loop.py:288-299)
             torch.nan_to_num(g, nan=0.0, posinf=1e5, neginf=-1e5, out=g)
             self.optims[k].step()
         nbytes = self._launched_bytes if multi else 0
-        self._arm_units()
+        if self.measure_comm:
+            self._pending_stalls = stalls      # resolved lazily (allreduce_exposed_ms): reading an event time synchronises
         self.last_allreduce_bytes = nbytes
+        self.last_allreduce_bytes_in_backward = self._launched_in_backward if multi else 0
+        self._arm_units()
         return nbytes
 
+    def _timed_wait(self, work):
+        """work.wait() bracketed so that the time the COMPUTE stream stood still for this collective can be read later:
+        a HIP event pair on the current stream (RCCL: wait() only makes the stream wait), wall clock on the CPU (gloo)."""
+        if self.device.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            work.wait()
+            e1.record()
+            return (e0, e1)
+        import time
+        t0 = time.perf_counter()
+        work.wait()
+        return (time.perf_counter() - t0) * 1e3
+
+    @property
+    def allreduce_exposed_ms(self):
+        """With measure_comm = True: how long the last step's compute stream was stalled waiting for all-reduce units --
+        what of the collective was NOT hidden under the backward / the earlier buckets' Adam (0 on one rank).  Reading it
+        synchronises the device."""
+        tot = 0.0
+        for st in getattr(self, "_pending_stalls", []):
+            if isinstance(st, tuple):
+                st[1].synchronize()
+                tot += st[0].elapsed_time(st[1])
+            else:
+                tot += st
+        return tot
+
     # ---- forward ------------------------------------------------------------------------------------------------------
-    def _scene_loss(self, batch, b, scene_id, attrs):
+    def _scene_features(self, batch, scene_ids):
+        """Plane-mean features of all local scenes [B * N, C] from ONE channel-last copy of the shared planes, the scenes'
+        latent modulation applied inside the gather (fused_planes)."""
+        from .decoder import planes_channels_last, planes_gather
+        planes_cl = planes_channels_last(self.planes, self.triplane_depth)
+        depth = self.triplane_depth or 1
+        mods = self.latents[scene_ids].view(len(scene_ids), self.plane_channels, depth).transpose(1, 2).contiguous()
+        return planes_gather(planes_cl, batch.positions, self.decoder.box_warp, self.plane_axes, self.triplane_depth, mod=mods)
+
+    def _scene_loss(self, batch, b, scene_id, attrs, feats=None):
         gs = GaussianModel(0)    # one container per in-flight scene (its tensors are saved by autograd until backward)
         if attrs is not None:
             gs._xyz, gs._scaling, gs._rotation, gs._opacity, color = attrs[b]
             gs._features_dc = color.unsqueeze(1)
         else:
-            planes = self.planes * self.latents[scene_id][None, :, None, None]
-            out = self.decoder_fwd(planes, batch.positions[b])
+            if feats is not None:
+                n = batch.positions.shape[1]
+                out = self.decoder_fwd(None, batch.positions[b], features=feats[b * n:(b + 1) * n])
+            else:
+                planes = self.planes * self.latents[scene_id][None, :, None, None]
+                out = self.decoder_fwd(planes, batch.positions[b])
             gs._xyz, gs._scaling, gs._rotation = out.xyz, out.scale, out.rotation
             gs._opacity, gs._features_dc = out.opacity, out.color.unsqueeze(1)
         fov = float(batch.fov_deg[b]) / 360 * 2 * math.pi
@@ -279,10 +373,11 @@ class DecoderTrainer:
         B = batch.positions.shape[0]
         scene_ids = batch.scene_id.tolist()
         attrs = None
+        feats = self._scene_features(batch, scene_ids) if self.fused_planes else None
         if self.fused_decoder:   # all local scenes through one decoder launch
             from .fused_decoder import split_attrs
-            attrs = split_attrs(self.decoder_fwd.forward_scenes(
-                [self.planes * self.latents[s][None, :, None, None] for s in scene_ids], batch.positions))
+            planes_list = None if feats is not None else [self.planes * self.latents[s][None, :, None, None] for s in scene_ids]
+            attrs = split_attrs(self.decoder_fwd.forward_scenes(planes_list, batch.positions, feats=feats))
         losses = []
         self._perc_images = []
         if self.use_streams and B > 1:
@@ -293,13 +388,13 @@ class DecoderTrainer:
                 st = self._streams[b]
                 st.wait_stream(main)                    # the decoder outputs / parameters come from the main stream
                 with torch.cuda.stream(st):
-                    losses.append(self._scene_loss(batch, b, scene_ids[b], attrs))
+                    losses.append(self._scene_loss(batch, b, scene_ids[b], attrs, feats))
             for b in range(B):
                 main.wait_stream(self._streams[b])
                 losses[b].record_stream(main)
         else:
             for b in range(B):
-                losses.append(self._scene_loss(batch, b, scene_ids[b], attrs))
+                losses.append(self._scene_loss(batch, b, scene_ids[b], attrs, feats))
         total = losses[0]
         for l in losses[1:]:
             total = total + l
@@ -312,6 +407,7 @@ class DecoderTrainer:
         return total
 
     def step(self, batch: SceneBatch) -> float:
+        self._arm_units()          # a previous step that raised inside its backward left units half-counted / in flight
         self.flat_grad.zero_()
         loss = self.local_loss(batch)
         loss.backward()

@@ -248,6 +248,22 @@ int ggd_trigrid_backward(ggd_ctx* ctx, void* stream, int32_t C, int32_t D, int32
                          const float* pos, int32_t N, float box_warp, const float* dout, float* dgrids_cl);
 
 /*
+ * The general form of the four entries above (they are thin wrappers of it): D = 0 selects the 2-D tri-plane form
+ * (axes must be 0), D >= 1 the tri-grid.  `mod` (NULL = none): a per-(depth, channel) modulation [max(D,1)][C] of the
+ * planes -- what is sampled is fl(texel * mod), i.e. the gather of `planes * code[None, :, None, None]` without that
+ * product ever being materialised (the training step's stand-in for per-scene planes of a shared backbone,
+ * main/decoder_models/sequential_decoder_reverse.py:89-99); the scatter returns the gradient w.r.t. the UNMODULATED
+ * planes.  accumulate != 0: dgrids_cl is added to instead of zero-filled first (several scenes into one gradient
+ * buffer).  Large N (>= 49152 points, C in {16, 32, 64}): the (point, plane) items are sorted by cell and summed in
+ * registers per run of equal cells, one group of atomics per run; otherwise one atomic per (point, tap, channel).
+ */
+int ggd_planes_gather(ggd_ctx* ctx, void* stream, const float* grids_cl, int32_t C, int32_t D, int32_t H, int32_t W,
+                      int32_t axes, const float* mod, const float* pos, int32_t N, float box_warp, float* out);
+int ggd_planes_scatter(ggd_ctx* ctx, void* stream, int32_t C, int32_t D, int32_t H, int32_t W, int32_t axes,
+                       const float* mod, const float* pos, int32_t N, float box_warp, const float* dout,
+                       float* dgrids_cl, int32_t accumulate);
+
+/*
  * GPU iso-surface point sampler -- the position generator of the decoder training step, replacing the CPU marching
  * cubes + trimesh + D2H/H2D hop of main/decoder_utils/target_dataloader.py:96-118,172-176: density grid sigma[n][n][n]
  * ([x][y][z], z fastest, main/marching_cube/sample.py:15-17) -> iso-surface at `level` (reference: 10) by marching

@@ -8,8 +8,10 @@ from gaussian_gan_decoder_amd.decoder import SequentialDecoderReverse, sample_fr
 pytestmark = pytest.mark.gpu
 
 
+# N >= 49152 with C in {16, 32, 64}: the sorted-run backward; smaller N or other C: one atomic per (point, tap, channel)
 @pytest.mark.parametrize("C,H,W,N", [(32, 64, 64, 10000), (32, 256, 256, 200001), (8, 16, 24, 777), (64, 32, 32, 4096),
-                                     (32, 64, 48, 30011), (16, 40, 40, 20000)])   # the last three sizes with C in {16, 32} take the binned backward
+                                     (32, 64, 48, 30011), (16, 40, 40, 60000), (64, 24, 40, 50001), (32, 512, 512, 300000),
+                                     (8, 32, 32, 70000)])
 def test_triplane_mean_matches_torch(native_lib, C, H, W, N):
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(C + N)
@@ -25,6 +27,70 @@ def test_triplane_mean_matches_torch(native_lib, C, H, W, N):
     ref.backward(gout)
     scale = max(1.0, ref_planes.grad.abs().max().item())
     assert (planes.grad - ref_planes.grad).abs().max().item() <= 1e-5 * scale * 10   # fp32 atomics: order-dependent sums
+
+
+def _trigrid_reference64(planes, pos, axes, D, mod=None):
+    """float64 autograd through torch's own 3-D grid_sample on the CPU: features and d(sum(features * gout)) / d planes."""
+    p64 = planes.detach().double().cpu().requires_grad_(True)
+    src = p64 if mod is None else p64 * mod.detach().double().cpu()[None, :, None, None]
+    return p64, sample_from_planes(src, pos.detach().double().cpu(), 1.0, axes, D).mean(0)
+
+
+@pytest.mark.parametrize("C,D,H,W,N,axes", [(32, 3, 256, 256, 500_000, "panohead"),   # the config-3 tri-grid: sorted runs
+                                            (32, 3, 64, 64, 60_000, "eg3d"), (16, 2, 40, 24, 70_001, "panohead"),
+                                            (64, 1, 32, 32, 50_000, "panohead"), (32, 5, 20, 28, 49_152, "panohead"),
+                                            (32, 3, 64, 64, 3_000, "panohead"), (8, 4, 16, 16, 60_000, "eg3d")])   # plain atomics
+def test_trigrid_gather_and_scatter_match_grid_sample_in_float64(native_lib, C, D, H, W, N, axes):
+    """PanoHead's 3-D grid_sample over the C x D tri-grids (PanoHead/training/volumetric_rendering/renderer.py:47-58),
+    forward and backward, against torch's grid_sample evaluated in float64: features within 2e-6, plane gradients within
+    2e-6 of the largest gradient element (fp32 sums of up to a few hundred terms in another order)."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C * 1000 + D * 100 + N % 97)
+    planes = torch.randn(3, C * D, H, W, generator=g)
+    # a head-like shell plus points outside the box (zero padding) and points exactly on texel centres / cell borders
+    d = torch.randn(N, 3, generator=g)
+    pos = 0.3 * d / d.norm(dim=1, keepdim=True) * (1.0 + 0.1 * torch.randn(N, 1, generator=g))
+    pos[: N // 50] = torch.rand(N // 50, 3, generator=g) * 1.3 - 0.65
+    pos[N // 50: N // 25] = ((torch.randint(0, W, (N // 25 - N // 50, 3), generator=g).float() + 0.5) / W) - 0.5
+    gout = torch.randn(N, C, generator=g)
+    p64, ref = _trigrid_reference64(planes, pos, axes, D)
+    (ref * gout.double()).sum().backward()
+    pg = planes.to(dev).requires_grad_(True)
+    out = triplane_mean(pg, pos.to(dev), 1.0, axes, D)
+    assert out.shape == (N, C)
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+    out.backward(gout.to(dev))
+    gref = p64.grad
+    err = (pg.grad.cpu().double() - gref).abs().max().item()
+    assert err <= 2e-6 * max(1.0, gref.abs().max().item()), (err, gref.abs().max().item())
+    assert gref.abs().max().item() > 1.0
+
+
+@pytest.mark.parametrize("C,D,H,W,N,B,axes", [(32, 3, 128, 128, 120_000, 3, "panohead"), (32, None, 128, 128, 100_000, 2, "eg3d"),
+                                              (16, 2, 32, 32, 5_000, 2, "panohead")])
+def test_modulated_scene_batch_gather_matches_materialised_planes(native_lib, C, D, H, W, N, B, axes):
+    """planes_gather on ONE channel-last copy of shared planes with per-scene modulations (the training step's fused form)
+    == gathering from the materialised `planes * code` of every scene: features and the gradient w.r.t. the shared planes
+    (all scenes summed into one buffer), against float64."""
+    from gaussian_gan_decoder_amd.decoder import planes_channels_last, planes_gather
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5 + N)
+    depth = D or 1
+    planes = torch.randn(3, C * depth, H, W, generator=g)
+    codes = 1.0 + 0.25 * torch.randn(B, C * depth, generator=g)
+    pos = torch.rand(B, N, 3, generator=g) * 0.9 - 0.45
+    gout = torch.randn(B * N, C, generator=g)
+    p64 = planes.double().requires_grad_(True)
+    ref = torch.cat([sample_from_planes(p64 * codes[b].double()[None, :, None, None], pos[b].double(), 1.0, axes, D).mean(0)
+                     for b in range(B)])
+    (ref * gout.double()).sum().backward()
+    pg = planes.to(dev).requires_grad_(True)
+    mods = codes.to(dev).view(B, C, depth).transpose(1, 2).contiguous()
+    out = planes_gather(planes_channels_last(pg, D), pos.to(dev), 1.0, axes, D, mod=mods)
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 3e-6 * max(1.0, ref.abs().max().item())
+    out.backward(gout.to(dev))
+    err = (pg.grad.cpu().double() - p64.grad).abs().max().item()
+    assert err <= 3e-6 * max(1.0, p64.grad.abs().max().item()), err
 
 
 def test_decoder_forward_backward_runs_on_gpu(native_lib):

@@ -60,11 +60,18 @@ def _half_step(tr, batch):
     return float(loss.detach())
 
 
+# the two plane formats of the reference's generators: EG3D tri-planes, PanoHead tri-grids (depth 3, PanoHead's plane axes:
+# main/train_pano2gaussian_decoder.py:43 default "panohead", PanoHead/train.py:230,318)
+PLANES = {"eg3d": dict(), "panohead": dict(plane_axes="panohead", triplane_depth=3)}
+
+
+@pytest.mark.parametrize("planes", ["eg3d", "panohead"])
 @pytest.mark.parametrize("fused_activations", [False, True], ids=["torch-getters", "fused-activations"])
-def test_composed_step_matches_the_oracle_backed_cpu_trainer(native_lib, fused_activations):
+def test_composed_step_matches_the_oracle_backed_cpu_trainer(native_lib, fused_activations, planes):
     from gaussian_gan_decoder_amd.train import make_scene_batch
     dev = torch.device("cuda:0")
-    cpu_tr, gpu_tr = _make("cpu"), _make(dev, fused_activations=fused_activations)
+    cpu_tr, gpu_tr = _make("cpu", **PLANES[planes]), _make(dev, fused_activations=fused_activations, **PLANES[planes])
+    assert gpu_tr.fused_planes and not cpu_tr.fused_planes   # HIP: modulation inside the gather; CPU: materialised planes
     assert torch.equal(_flat(cpu_tr.params), _flat(gpu_tr.params)), "the two trainers must start from the same parameters"
     for it in range(2):
         cb = make_scene_batch([0, 1], N_POINTS, SMALL["image_size"], "cpu", seed=it)
@@ -97,16 +104,17 @@ def test_composed_step_matches_the_oracle_backed_cpu_trainer(native_lib, fused_a
         d = (pc - pg).abs()
         assert float(d.max()) <= 1e-4, (it, float(d.max()))
         assert float((d > 2e-6).float().mean()) <= 2e-3, (it, float((d > 2e-6).float().mean()))
-    init = _flat(_make("cpu").params)
+    init = _flat(_make("cpu", **PLANES[planes]).params)
     assert float((pg - init).abs().max()) > 1e-5      # the steps trained something
 
 
-def test_composed_step_with_the_fused_decoder(native_lib):
+@pytest.mark.parametrize("planes", ["eg3d", "panohead"])
+def test_composed_step_with_the_fused_decoder(native_lib, planes):
     """Same composition with the bf16-MFMA decoder kernels in place of the PyTorch modules: the loss within 2 % and the
     gradients within bf16-operand accuracy (relative L2 per parameter tensor) of the oracle-backed CPU trainer."""
     from gaussian_gan_decoder_amd.train import make_scene_batch
     dev = torch.device("cuda:0")
-    cpu_tr, gpu_tr = _make("cpu"), _make(dev, fused_decoder=True, fused_activations=True)
+    cpu_tr, gpu_tr = _make("cpu", **PLANES[planes]), _make(dev, fused_decoder=True, fused_activations=True, **PLANES[planes])
     cb = make_scene_batch([0, 1], N_POINTS, SMALL["image_size"], "cpu", seed=0)
     gb = make_scene_batch([0, 1], N_POINTS, SMALL["image_size"], dev, seed=0)
     lc, lg = _half_step(cpu_tr, cb), _half_step(gpu_tr, gb)
@@ -125,13 +133,15 @@ def test_composed_step_with_the_fused_decoder(native_lib):
         assert rel <= 0.12, (tuple(p.shape), rel)
 
 
-def test_composed_step_with_the_fused_decoder_at_fp32_precision(native_lib):
+@pytest.mark.parametrize("planes", ["eg3d", "panohead"])
+def test_composed_step_with_the_fused_decoder_at_fp32_precision(native_lib, planes):
     """The composition with the split-operand (reference-precision) decoder kernels: loss within 1e-5 and every parameter
     tensor's gradient within 5e-3 of its largest element of the oracle-backed CPU trainer (whose decoder is the fp32 torch
     module)."""
     from gaussian_gan_decoder_amd.train import make_scene_batch
     dev = torch.device("cuda:0")
-    cpu_tr, gpu_tr = _make("cpu"), _make(dev, fused_decoder=True, fused_activations=True, decoder_precision="fp32")
+    cpu_tr = _make("cpu", **PLANES[planes])
+    gpu_tr = _make(dev, fused_decoder=True, fused_activations=True, decoder_precision="fp32", **PLANES[planes])
     cb = make_scene_batch([0, 1], N_POINTS, SMALL["image_size"], "cpu", seed=0)
     gb = make_scene_batch([0, 1], N_POINTS, SMALL["image_size"], dev, seed=0)
     lc, lg = _half_step(cpu_tr, cb), _half_step(gpu_tr, gb)
@@ -155,10 +165,13 @@ def _curve(tr, steps, batch_fn):
     return np.asarray(out)
 
 
-def test_config3_size_trains(native_lib):
-    """BASELINE config 3: batch = 4 scenes x 500 000 points at 512 x 512, L1 + L2 + SSIM + Sobel + the perceptual slot,
-    backward through the raster, Adam -- 30 steps with the fp32 PyTorch decoder and with the fused bf16-MFMA decoder on
-    the same 4 scenes (bf16 and split-operand fp32 precision): finite, the loss decreases, the curves agree within 5 %."""
+@pytest.mark.parametrize("planes", ["panohead", "eg3d"])
+def test_config3_size_trains(native_lib, planes):
+    """BASELINE config 3 ("full train_pano2gaussian_decoder.py step (PanoHead), batch=4, 512^2"): batch = 4 scenes x 500 000
+    points at 512 x 512, L1 + L2 + SSIM + Sobel + the perceptual slot, backward through the raster, Adam -- 30 steps with
+    the fp32 PyTorch decoder and with the fused bf16-MFMA decoder on the same 4 scenes (bf16 and split-operand fp32
+    precision): finite, the loss decreases, the curves agree within 5 %.  "panohead": the named form, tri-grids
+    [3, 96, 256, 256] sampled with the 3-D grid_sample; "eg3d": the tri-plane form beside it."""
     from gaussian_gan_decoder_amd.train import DecoderTrainer, make_scene_batch
     dev = torch.device("cuda:0")
     steps, B, N, S = 30, 4, 500_000, 512
@@ -167,7 +180,7 @@ def test_config3_size_trains(native_lib):
     for name, kw in (("fp32", dict()), ("fused", dict(fused_decoder=True, fused_activations=True)),
                      ("fused-fp32", dict(fused_decoder=True, fused_activations=True, decoder_precision="fp32"))):
         tr = DecoderTrainer(dev, n_scenes_total=B, image_size=S, seed=11, lr=1e-3, perceptual_weight=0.05,
-                            perceptual_width_div=4, backbone_params=100_000, **kw)
+                            perceptual_width_div=4, backbone_params=100_000, **kw, **PLANES[planes])
         c = _curve(tr, steps, lambda it: batch)
         torch.cuda.synchronize()
         print(f"\n  loss {name:5s}:", np.array2string(c[::3], precision=5))
