@@ -346,8 +346,7 @@ class DecoderTrainer:
             gs._features_dc = color.unsqueeze(1)
         else:
             if feats is not None:
-                n = batch.positions.shape[1]
-                out = self.decoder_fwd(None, batch.positions[b], features=feats[b * n:(b + 1) * n])
+                out = self.decoder_fwd(None, batch.positions[b], features=feats[b])
             else:
                 planes = self.planes * self.latents[scene_id][None, :, None, None]
                 out = self.decoder_fwd(planes, batch.positions[b])
@@ -374,6 +373,10 @@ class DecoderTrainer:
         scene_ids = batch.scene_id.tolist()
         attrs = None
         feats = self._scene_features(batch, scene_ids) if self.fused_planes else None
+        if feats is not None and not self.fused_decoder:
+            # per-scene rows for the PyTorch decoder: unbind's backward is ONE stack (slices would each zero-fill and add a
+            # full [B * N, C] gradient)
+            feats = feats.view(B, batch.positions.shape[1], -1).unbind(0)
         if self.fused_decoder:   # all local scenes through one decoder launch
             from .fused_decoder import split_attrs
             planes_list = None if feats is not None else [self.planes * self.latents[s][None, :, None, None] for s in scene_ids]

@@ -24,5 +24,17 @@ def test_bench_two_ranks_on_one_gpu(native_lib):
     assert len(lines) == 1, res.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["value"] > 0
-    assert d["train"]["global_batch"] == 4 and d["train"]["allreduce_bytes"] > 0
     assert d["train_fused_decoder"]["iters_per_s"] > 0
+    # 8-GPU readiness (BASELINE config 5): every train section, in both plane formats, all-reduces the reference's payload --
+    # decoder + planes + backbone stand-in = 29 763 294 fp32 gradients, each exactly once -- and at least 75 % of those bytes
+    # were handed to the collective from inside the backward (gradient hooks), not after it
+    for key in ("train", "train_fused_decoder", "train_fused_decoder_fp32"):
+        for sec in (d[key], d[key]["eg3d_planes"]):
+            assert sec["global_batch"] == 4
+            assert sec["parameters_all_reduced"] == 29_763_294, (key, sec["planes"])
+            assert sec["allreduce_bytes"] == 4 * 29_763_294, (key, sec["planes"], sec["allreduce_bytes"])
+            assert sec["allreduce_bytes_launched_in_backward"] >= 0.75 * sec["allreduce_bytes"], (key, sec["planes"])
+            assert sec["allreduce_exposed_ms"] >= 0.0
+    assert "PanoHead" in d["train"]["planes"] and "EG3D" in d["train"]["eg3d_planes"]["planes"]
+    wf = d["whole_frame"]
+    assert 0 < wf["algorithmic_bytes_path"] < wf["contract_formula_bytes"]

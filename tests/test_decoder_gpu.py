@@ -42,8 +42,10 @@ def _trigrid_reference64(planes, pos, axes, D, mod=None):
                                             (32, 3, 64, 64, 3_000, "panohead"), (8, 4, 16, 16, 60_000, "eg3d")])   # plain atomics
 def test_trigrid_gather_and_scatter_match_grid_sample_in_float64(native_lib, C, D, H, W, N, axes):
     """PanoHead's 3-D grid_sample over the C x D tri-grids (PanoHead/training/volumetric_rendering/renderer.py:47-58),
-    forward and backward, against torch's grid_sample evaluated in float64: features within 2e-6, plane gradients within
-    2e-6 of the largest gradient element (fp32 sums of up to a few hundred terms in another order)."""
+    forward and backward, against (a) torch's own fp32 grid_sample + autograd on the GPU -- same fp32 texel coordinates, so
+    only the summation order differs: features 1e-5, plane gradients 1e-5 of the largest element -- and (b) the same ops in
+    float64 on the CPU: an fp32 texel coordinate of magnitude ~W carries W * 2^-24 of rounding, which a unit step between
+    texels turns into ~1e-5 at W = 256: 1e-4."""
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(C * 1000 + D * 100 + N % 97)
     planes = torch.randn(3, C * D, H, W, generator=g)
@@ -55,15 +57,19 @@ def test_trigrid_gather_and_scatter_match_grid_sample_in_float64(native_lib, C, 
     gout = torch.randn(N, C, generator=g)
     p64, ref = _trigrid_reference64(planes, pos, axes, D)
     (ref * gout.double()).sum().backward()
+    p32 = planes.to(dev).requires_grad_(True)
+    ref32 = sample_from_planes(p32, pos.to(dev), 1.0, axes, D).mean(0)
+    ref32.backward(gout.to(dev))
     pg = planes.to(dev).requires_grad_(True)
     out = triplane_mean(pg, pos.to(dev), 1.0, axes, D)
     assert out.shape == (N, C)
-    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+    assert (out.detach() - ref32.detach()).abs().max().item() <= 1e-5
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
     out.backward(gout.to(dev))
-    gref = p64.grad
-    err = (pg.grad.cpu().double() - gref).abs().max().item()
-    assert err <= 2e-6 * max(1.0, gref.abs().max().item()), (err, gref.abs().max().item())
-    assert gref.abs().max().item() > 1.0
+    gmax = max(1.0, p64.grad.abs().max().item())
+    assert (pg.grad - p32.grad).abs().max().item() <= 1e-5 * gmax
+    assert (pg.grad.cpu().double() - p64.grad).abs().max().item() <= 1e-4 * gmax
+    assert gmax > 1.0
 
 
 @pytest.mark.parametrize("C,D,H,W,N,B,axes", [(32, 3, 128, 128, 120_000, 3, "panohead"), (32, None, 128, 128, 100_000, 2, "eg3d"),
@@ -87,10 +93,18 @@ def test_modulated_scene_batch_gather_matches_materialised_planes(native_lib, C,
     pg = planes.to(dev).requires_grad_(True)
     mods = codes.to(dev).view(B, C, depth).transpose(1, 2).contiguous()
     out = planes_gather(planes_channels_last(pg, D), pos.to(dev), 1.0, axes, D, mod=mods)
-    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 3e-6 * max(1.0, ref.abs().max().item())
+    # fp32 texel coordinates against float64 ones: W * 2^-24 of coordinate rounding -> 1e-4 (see the test above); the same
+    # computation with materialised planes in fp32 on the GPU: summation order only
+    p32 = planes.to(dev).requires_grad_(True)
+    ref32 = torch.cat([sample_from_planes(p32 * codes[b].to(dev)[None, :, None, None], pos[b].to(dev), 1.0, axes, D).mean(0)
+                       for b in range(B)])
+    ref32.backward(gout.to(dev))
+    assert (out.detach() - ref32.detach()).abs().max().item() <= 1e-5
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
     out.backward(gout.to(dev))
-    err = (pg.grad.cpu().double() - p64.grad).abs().max().item()
-    assert err <= 3e-6 * max(1.0, p64.grad.abs().max().item()), err
+    gmax = max(1.0, p64.grad.abs().max().item())
+    assert (pg.grad - p32.grad).abs().max().item() <= 1e-5 * gmax
+    assert (pg.grad.cpu().double() - p64.grad).abs().max().item() <= 1e-4 * gmax
 
 
 def test_decoder_forward_backward_runs_on_gpu(native_lib):
