@@ -551,6 +551,7 @@ def main():
             nparam = sum(p.numel() for p in tr.params)
             ar = tr.last_allreduce_bytes
             del tr
+            torch.cuda.empty_cache()   # the next configuration starts from a clean allocator (z / dz buffers are GBs)
             return {"iters_per_s": args.train_iters / t_train,
                     "scenes_per_s": args.train_iters * spg * world / t_train,
                     "ms_per_iter": t_train / args.train_iters * 1e3, "global_batch": spg * world,

@@ -434,200 +434,58 @@ all_done:
   }
 }
 
-// Backward blend.  Same wave/tile mapping as the forward; records are visited back-to-front from the last position
-// any pixel of the tile contributed to.  The pixel body is SELECT-FREE and packed (two pixels per VALU issue):
-// a pixel that does not see the record (culled, beyond its n_contrib, alpha < 1/255) gets alpha = G = 0, which makes
-// every state update an exact no-op (T/(1-0) = T; the pending (last_alpha, last_color) pair is folded into the
-// running colour one record early and then applied with weight 0), so no per-pixel branches or selects on the
-// 8 words of recurrence state are needed.  1/(1-alpha) is one v_rcp + one Newton step, shared by both divisions.
-template <int EXP_MODE, bool CULL, int PXL>
-__global__ __launch_bounds__(64) void blend_backward_kernel(
-    int W, int H, int gx, int T_tiles, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ list,
-    const uint32_t* __restrict__ ranges, const float* __restrict__ bg, const float* __restrict__ final_T,
-    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
-  __shared__ float4 s_rec[64 * 3];
-  __shared__ float s_sum[64 * 9];  // [record slot][component], written by lane 63 only
-  const int lane = threadIdx.x;
-  constexpr int NP = PXL / 2;  // pixel pairs per lane
-  const WaveGeom<PXL> g(gx, T_tiles, ranges);
-  const bool row_in = g.py < H;
-  const size_t HW = (size_t)H * W;
-  const size_t pix0 = (size_t)g.py * W + g.px0;
+// Backward blend: the per-record update of ONE pixel, shared by the two kernel forms below.  Records are visited back to
+// front; the body is SELECT-FREE: a pixel that does not see the record (culled, beyond its n_contrib, alpha < 1/255) gets
+// alpha = G = 0, which makes every state update an exact no-op (T / (1 - 0) = T, acc + 0 * (c - acc) = acc), so no per-pixel
+// branches or selects on the recurrence state are needed.  1/(1 - alpha) is one v_rcp + one Newton step.
+//   * The colour behind the record is folded in RIGHT AFTER its use: the published form keeps (last_alpha, last_color) and
+//     folds one record late, accum = la * lc + (1 - la) * accum -- 17 instructions per update; with d = c - accum (needed for
+//     dL/dalpha anyway) the same value is accum + alpha * d: 9 instructions and two words less state per pixel.
+//   * The mean gradient leaves the pixel loop as the two sums  sum(dL/dalpha * G * dx), sum(dL/dalpha * G * dy); the conic's
+//     2 x 2 matrix, the opacity, the -1/2 and the 0.5 W / 0.5 H of the pixel-to-NDC map are applied once per (record,
+//     component) by the flush, not per pixel.
+struct BwdPixel { float T, nTfin, bgdot, acc[3], gpx[3]; };
 
-  // per-pixel state, packed as pairs: [p] = pixels (2p, 2p+1) of the lane
-  f2 T[NP], nTfin[NP], la[NP], bgdot[NP], acc[NP][3], lastc[NP][3], gpx[NP][3];
-  f2 px[NP];
+template <int EXP_MODE>
+__device__ __forceinline__ uint64_t bwd_update(BwdPixel& st, float pw, float dx, float dy, uint64_t need, float opacity,
+                                               const float (&col)[3], float (&s)[8], float& sop) {
+  const float g0 = blend_exp<EXP_MODE>(pw);
+  const float a0 = fminf(0.99f, opacity * g0);
+  const uint64_t live = need & ~__ballot(pw > 0.0f) & ~__ballot(a0 < ALPHA_FLOOR);
+  const float G = sel_or_zero(g0, live), alpha = sel_or_zero(a0, live);
+  const float om = 1.0f - alpha;
+  float inv = __builtin_amdgcn_rcpf(om);
+  inv = __builtin_fmaf(inv, __builtin_fmaf(-om, inv, 1.0f), inv);
+  st.T = st.T * inv;
+  const float dchannel_dcolor = alpha * st.T;
+  float dL_dalpha = 0.0f;
 #pragma unroll
-  for (int p = 0; p < NP; ++p) px[p] = (f2){(float)(g.px0 + 2 * p), (float)(g.px0 + 2 * p + 1)};
-  uint32_t lastn[PXL];
-  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  const float pyf = (float)g.py;
-  uint32_t maxn = 0;
-#pragma unroll
-  for (int k = 0; k < PXL; ++k) {
-    const bool in = row_in && (g.px0 + k) < W;
-    const float tf = in ? final_T[pix0 + k] : 0.0f;
-    lastn[k] = in ? n_contrib[pix0 + k] : 0u;
-    maxn = max(maxn, lastn[k]);
-    float gg[3];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) gg[ch] = in ? dL_dpix[ch * HW + pix0 + k] : 0.0f;
-    const float bd = (bg0 * gg[0] + bg1 * gg[1]) + bg2 * gg[2];
-    const int p = k >> 1;
-    if (k & 1) {
-      T[p].y = tf; nTfin[p].y = -tf; bgdot[p].y = bd;
-      gpx[p][0].y = gg[0]; gpx[p][1].y = gg[1]; gpx[p][2].y = gg[2];
-    } else {
-      T[p].x = tf; nTfin[p].x = -tf; bgdot[p].x = bd;
-      gpx[p][0].x = gg[0]; gpx[p][1].x = gg[1]; gpx[p][2].x = gg[2];
-    }
+  for (int ch = 0; ch < 3; ++ch) {
+    const float d = col[ch] - st.acc[ch];
+    dL_dalpha = __builtin_fmaf(d, st.gpx[ch], dL_dalpha);
+    fma_into(st.acc[ch], alpha, d);                       // in place: the culled path carries no copy
+    s[ch] = dchannel_dcolor * st.gpx[ch];
   }
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    la[p] = (f2){0.0f, 0.0f};
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) { acc[p][ch] = (f2){0.0f, 0.0f}; lastc[p][ch] = (f2){0.0f, 0.0f}; }
-  }
-  // wave-uniform number of list positions anyone in the tile contributed to
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) maxn = max(maxn, (uint32_t)__shfl_xor((int)maxn, d, 64));
-  if (maxn == 0) return;
-  const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-  constexpr int LPR = WaveGeom<PXL>::LPR, ROWS = WaveGeom<PXL>::BH;
-  const float twx0 = (float)(g.px0 - (lane % LPR) * PXL), twy0 = (float)(g.py - lane / LPR);  // the wave's pixel rectangle
+  dL_dalpha = __builtin_fmaf(st.nTfin * inv, st.bgdot, dL_dalpha * st.T);
+  const float wx = (G * dx) * dL_dalpha, wy = (G * dy) * dL_dalpha;
+  s[3] = wx * dx;
+  s[4] = wx * dy;
+  s[5] = wy * dy;
+  s[6] = wx;
+  s[7] = wy;
+  sop = G * dL_dalpha;
+  return live;
+}
 
-  uint32_t cend = g.lo + maxn;  // one past the last position that matters
-  while (cend > g.lo) {
-    const uint32_t cstart = (cend - g.lo > 64u) ? cend - 64u : g.lo;
-    const int n = (int)(cend - cstart);
-    __syncthreads();
-    bool keep = false;
-    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
-    if (lane < n) {
-      const uint32_t my_id = list[cstart + lane];
-      const float4* p = reinterpret_cast<const float4*>(splat + my_id);
-      const float4 r0 = p[0], r1 = p[1], r2 = p[2];   // x y hA nB | hC thr opacity r | g b ex ey
-      // staged as {x, y, A, B} {C, opacity, r, g} {b, power threshold, Gaussian id, 0-based list position}
-      // (A = -2 hA, B = -nB, C = -2 hC: exact)
-      q0 = make_float4(r0.x, r0.y, -2.0f * r0.z, -r0.w);
-      q1 = make_float4(-2.0f * r1.x, r1.z, r1.w, r2.x);
-      q2 = make_float4(r2.y, CULL ? r1.y : -__builtin_huge_valf(), __uint_as_float(my_id),
-                       __uint_as_float((cstart - g.lo) + (uint32_t)lane));
-      keep = CULL ? record_box_hits(r0.x, r0.y, r2.z, r2.w, twx0, twx0 + 15.0f, twy0, twy0 + (float)(ROWS - 1)) : true;
-    }
-    const uint64_t kept = __ballot(keep);
-    const int nk = __popcll(kept);
-    if (keep) {  // compacted, order preserved
-      const int slot = __popcll(kept & ((1ull << lane) - 1ull));
-      s_rec[slot * 3 + 0] = q0; s_rec[slot * 3 + 1] = q1; s_rec[slot * 3 + 2] = q2;
-    }
-    __syncthreads();
-    uint64_t touched = 0;
-    for (int j = nk - 1; j >= 0; --j) {
-      const float4 a = s_rec[j * 3 + 0];                                         // x, y, conA, conB
-      const float4 b = s_rec[j * 3 + 1];                                         // conC, opacity, r, g
-      const float4 c4 = s_rec[j * 3 + 2];                                        // b, power threshold, id, position
-      const float2 c2 = make_float2(c4.x, c4.y);
-      const uint32_t pos0 = __float_as_uint(c4.w);  // 0-based position in the tile's list
-      const float col[3] = {b.z, b.w, c2.x};
-      const float dy = a.y - pyf;
-      const float hA = -0.5f * a.z, nBdy = (-a.w) * dy, hCdy2 = ((-0.5f * b.x) * dy) * dy;
-      const f2 gxx = {a.x, a.x};
-      f2 dx[NP], pw[NP];
-      bool need[PXL];
-      bool lane_need = false;
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        dx[p] = gxx - px[p];
-        pw[p] = gauss_power2(hA, nBdy, hCdy2, dx[p]);
-        need[2 * p] = (pos0 < lastn[2 * p]) && (pw[p].x >= c2.y);
-        need[2 * p + 1] = (pos0 < lastn[2 * p + 1]) && (pw[p].y >= c2.y);
-        lane_need = lane_need || need[2 * p] || need[2 * p + 1];
-      }
-      if (__ballot(lane_need) == 0ull) continue;  // nobody in the wave saw this Gaussian
-      f2 sc[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, sop = {0.f, 0.f}, scA = {0.f, 0.f}, scB = {0.f, 0.f},
-         scC = {0.f, 0.f}, smx = {0.f, 0.f}, smy = {0.f, 0.f};
-      bool any = false;
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        // exact per-pixel visibility test, then alpha = G = 0 for pixels that do not see the record
-        f2 G, alpha;
-        {
-          const float g0 = blend_exp<EXP_MODE>(pw[p].x), g1 = blend_exp<EXP_MODE>(pw[p].y);
-          const float a0 = fminf(0.99f, b.y * g0), a1 = fminf(0.99f, b.y * g1);
-          const bool l0 = need[2 * p] && !(pw[p].x > 0.0f) && !(a0 < ALPHA_FLOOR);
-          const bool l1 = need[2 * p + 1] && !(pw[p].y > 0.0f) && !(a1 < ALPHA_FLOOR);
-          any = any || l0 || l1;
-          G = (f2){l0 ? g0 : 0.0f, l1 ? g1 : 0.0f};
-          alpha = (f2){l0 ? a0 : 0.0f, l1 ? a1 : 0.0f};
-        }
-        const f2 om = 1.0f - alpha;
-        f2 inv;
-        {
-          float i0 = __builtin_amdgcn_rcpf(om.x), i1 = __builtin_amdgcn_rcpf(om.y);
-          i0 = __builtin_fmaf(i0, __builtin_fmaf(-om.x, i0, 1.0f), i0);
-          i1 = __builtin_fmaf(i1, __builtin_fmaf(-om.y, i1, 1.0f), i1);
-          inv = (f2){i0, i1};
-        }
-        // Explicit packed FMAs (the build runs with -ffp-contract=off); the per-record constants -- opacity,
-        // -1/2, the 0.5 W / 0.5 H of the pixel-to-NDC map and the minus sign of dG/d(delta) -- are applied once to the
-        // reduced sums below instead of to every pixel.
-        T[p] = T[p] * inv;
-        const f2 dchannel_dcolor = alpha * T[p];
-        const f2 oml = 1.0f - la[p];
-        f2 dL_dalpha = {0.0f, 0.0f};
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          acc[p][ch] = __builtin_elementwise_fma(la[p], lastc[p][ch], oml * acc[p][ch]);
-          lastc[p][ch] = (f2){col[ch], col[ch]};
-          dL_dalpha = __builtin_elementwise_fma(col[ch] - acc[p][ch], gpx[p][ch], dL_dalpha);
-          sc[ch] = __builtin_elementwise_fma(dchannel_dcolor, gpx[p][ch], sc[ch]);
-        }
-        la[p] = alpha;
-        dL_dalpha = __builtin_elementwise_fma(nTfin[p] * inv, bgdot[p], dL_dalpha * T[p]);
-        const f2 gdx = G * dx[p], gdy = G * dy;
-        const f2 ex = __builtin_elementwise_fma(gdy, (f2){a.w, a.w}, gdx * a.z);   // -dG/d(delta x)
-        const f2 ey = __builtin_elementwise_fma(gdx, (f2){a.w, a.w}, gdy * b.x);   // -dG/d(delta y)
-        smx = __builtin_elementwise_fma(dL_dalpha, ex, smx);
-        smy = __builtin_elementwise_fma(dL_dalpha, ey, smy);
-        const f2 wx = gdx * dL_dalpha, wy = gdy * dL_dalpha;
-        scA = __builtin_elementwise_fma(wx, dx[p], scA);
-        scB = __builtin_elementwise_fma(wx, (f2){dy, dy}, scB);
-        scC = __builtin_elementwise_fma(wy, (f2){dy, dy}, scC);
-        sop = __builtin_elementwise_fma(G, dL_dalpha, sop);
-      }
-      if (__ballot(any) != 0ull) {  // wave-uniform: somebody in the tile saw this Gaussian
-        touched |= 1ull << j;
-        float t[9] = {sc[0].x + sc[0].y, sc[1].x + sc[1].y, sc[2].x + sc[2].y, sop.x + sop.y, scA.x + scA.y,
-                      scB.x + scB.y, scC.x + scC.y, smx.x + smx.y, smy.x + smy.y};
-        ggd_wave_sum9_to63(t);
-        const float nho = -0.5f * b.y;   // d alpha / d G = opacity; d G / d conic = -1/2 G d d^T
-        const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = nho * t[4], t5 = nho * t[5], t6 = nho * t[6],
-                    t7 = (-b.y * ddelx_dx) * t[7], t8 = (-b.y * ddely_dy) * t[8];
-        if (lane == 63) {
-          float* o = s_sum + j * 9;
-          o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = t5; o[6] = t6; o[7] = t7; o[8] = t8;
-        }
-      }
-    }
-    __syncthreads();
-    if (lane < nk && ((touched >> lane) & 1ull)) {
-      const float* o = s_sum + lane * 9;
-      const size_t id = __float_as_uint(s_rec[lane * 3 + 2].z);
-      // one 48-byte accumulator record per Gaussian (GGD_ACC_*): the 9 atomics of a record land in one cache line
-      float* a = grad_acc + GGD_ACC_FLOATS * id;
-      atomicAdd(a + GGD_ACC_COLOR + 0, o[0]);
-      atomicAdd(a + GGD_ACC_COLOR + 1, o[1]);
-      atomicAdd(a + GGD_ACC_COLOR + 2, o[2]);
-      atomicAdd(a + GGD_ACC_OPACITY, o[3]);
-      atomicAdd(a + GGD_ACC_CONIC + 0, o[4]);
-      atomicAdd(a + GGD_ACC_CONIC + 1, o[5]);
-      atomicAdd(a + GGD_ACC_CONIC + 2, o[6]);
-      atomicAdd(a + GGD_ACC_MEAN2D + 0, o[7]);
-      atomicAdd(a + GGD_ACC_MEAN2D + 1, o[8]);
-    }
-    cend = cstart;
-  }
+// one (record, component) of the flush: v = the component's reduced sum (for the two mean components the pair of sums),
+// comp in accumulator-record order (conic A B C | opacity | mean x y | colour r g b)
+__device__ __forceinline__ float bwd_scale(int comp, float v, float swx, float swy, float hA, float nB, float hC, float op,
+                                           float ddelx_dx, float ddely_dy) {
+  // d alpha / d G = opacity; d G / d conic = -1/2 G d d^T; d G / d mean = -G * conic * d, conic = (-2 hA, -nB, -2 hC)
+  if (comp < 3) return (-0.5f * op) * v;
+  if (comp == 4) return (op * ddelx_dx) * __builtin_fmaf(2.0f * hA, swx, nB * swy);
+  if (comp == 5) return (op * ddely_dy) * __builtin_fmaf(2.0f * hC, swy, nB * swx);
+  return v;
 }
 
 // Nine wave sums with no LDS round trip: the eight of wave_reduce8_transposed plus a ninth that takes four all-lane DPP
@@ -679,59 +537,47 @@ __device__ __forceinline__ float wave_reduce9_swap(float (&v)[8], float ninth, u
   return v[0];
 }
 
-// ---- backward blend, tile form: the waves of a tile in ONE workgroup, PXL pixels per lane ---------------------------
-// PXL = 1: four waves, each an 8x8 quarter (the forward's shape: finest culling, ~60 VGPRs -> 8 waves per SIMD, 16 k waves
-// for 4096 tiles); PXL = 2: two waves, each a 16x8 half.  Per round of 64 list entries every wave gathers the records
-// itself (the other waves' copies hit L2), pre-culls them against its own rectangle and stages the survivors; the NEXT
-// round's gather is issued before the current round is blended (the two dependent global loads of a round were the
-// largest stall of the first version).  Staged records are walked back to front in groups of 8 as straight-line
-// code (list padded with never-visible records, see the forward).  Per-record sums: transposed butterfly, parked in LDS
-// per wave, combined over the waves by the flush -> one float atomic per (tile, Gaussian, component).
-template <int EXP_MODE, bool CULL, int PXL>
-__global__ __launch_bounds__(256 / PXL) void blend_backward_tile_kernel(
+// ---- backward blend, tile form: the four 8x8 quarter waves of a tile in ONE workgroup --------------------------------
+// (~60 VGPRs -> 8 waves per SIMD.)  Per round of 64 list entries every wave gathers the records itself (the other waves'
+// copies hit L2), pre-culls them against its own rectangle and stages the survivors; the NEXT round's gather is issued
+// before the current round is blended.  Staged records are walked back to front in groups of 8 as straight-line code (list
+// padded with never-visible records, see the forward).  Per-record sums: transposed butterfly, parked in LDS per wave,
+// combined over the waves by the flush -> one float atomic per (tile, Gaussian, component).
+template <int EXP_MODE, bool CULL>
+__global__ __launch_bounds__(256) void blend_backward_tile_kernel(
     int W, int H, int gx, int gy, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ list,
     const uint32_t* __restrict__ ranges, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
-  constexpr int NW = 4 / PXL;
+  constexpr int NW = 4;
   __shared__ float4 s_rec[NW][64 * 3];
   // per-round results are double-buffered: a round's flush reads buffer `par` while early waves already fill the other
   // one, so a round costs ONE workgroup barrier (everybody finished the round), not two
   __shared__ float s_sum[2][NW][64][9];
   __shared__ uint32_t s_id[2][64];
-  __shared__ float s_op[2][64];
+  __shared__ float4 s_cop[2][64];      // hA, nB, hC, opacity of the round's records (the flush applies them)
   __shared__ uint32_t s_touch[2][NW][2];
   __shared__ uint32_t s_maxn[NW];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int tile, sub_unused;
   ggd_block_to_tile((int)blockIdx.x, 1, gx, gy, gx * gy, tile, sub_unused);
   const int tx = tile % gx, ty = tile / gx;
-  const int qx = PXL == 1 ? (wv & 1) : 0, qy = PXL == 1 ? (wv >> 1) : wv;
-  const int px0 = tx * 16 + qx * 8 + (lane & 7) * PXL, py = ty * 16 + qy * 8 + (lane >> 3);
+  const int qx = wv & 1, qy = wv >> 1;
+  const int px0 = tx * 16 + qx * 8 + (lane & 7), py = ty * 16 + qy * 8 + (lane >> 3);
   const uint2 rg = reinterpret_cast<const uint2*>(ranges)[tile];
-  const bool row_in = py < H;
+  const bool in = py < H && px0 < W;
   const size_t HW = (size_t)H * W;
   const size_t pix0 = (size_t)py * W + px0;
 
-  float T[PXL], nTfin[PXL], la[PXL], bgdot[PXL], acc[PXL][3], lastc[PXL][3], gpx[PXL][3], px[PXL];
-  uint32_t lastn[PXL];
+  BwdPixel st;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  const float pyf = (float)py;
-  uint32_t maxn = 0;
+  const float pxf = (float)px0, pyf = (float)py;
+  const float tf = in ? final_T[pix0] : 0.0f;
+  const uint32_t lastn = in ? n_contrib[pix0] : 0u;
 #pragma unroll
-  for (int k = 0; k < PXL; ++k) {
-    const bool in = row_in && (px0 + k) < W;
-    const float tf = in ? final_T[pix0 + k] : 0.0f;
-    lastn[k] = in ? n_contrib[pix0 + k] : 0u;
-    maxn = max(maxn, lastn[k]);
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      gpx[k][ch] = in ? dL_dpix[ch * HW + pix0 + k] : 0.0f;
-      acc[k][ch] = 0.0f; lastc[k][ch] = 0.0f;
-    }
-    bgdot[k] = (bg0 * gpx[k][0] + bg1 * gpx[k][1]) + bg2 * gpx[k][2];
-    T[k] = tf; nTfin[k] = -tf; la[k] = 0.0f;
-    px[k] = (float)(px0 + k);
-  }
+  for (int ch = 0; ch < 3; ++ch) { st.gpx[ch] = in ? dL_dpix[ch * HW + pix0] : 0.0f; st.acc[ch] = 0.0f; }
+  st.bgdot = (bg0 * st.gpx[0] + bg1 * st.gpx[1]) + bg2 * st.gpx[2];
+  st.T = tf; st.nTfin = -tf;
+  uint32_t maxn = lastn;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) maxn = max(maxn, (uint32_t)__shfl_xor((int)maxn, d, 64));
   if (lane == 0) s_maxn[wv] = maxn;
@@ -742,11 +588,11 @@ __global__ __launch_bounds__(256 / PXL) void blend_backward_tile_kernel(
   if (maxn == 0) return;
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
   const float wx0 = (float)(tx * 16 + qx * 8), wy0 = (float)(ty * 16 + qy * 8);   // this wave's pixel rectangle
-  const float wx1 = wx0 + (float)(8 * PXL - 1), wy1 = wy0 + 7.0f;
+  const float wx1 = wx0 + 7.0f, wy1 = wy0 + 7.0f;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   float4* rec = s_rec[wv];
   const bool is_writer = (lane & 19) == 0 || lane == 1;
-  // reduction output index (colour r g b | conic A B C | mean x y | opacity) -> slot in the accumulator record's order
+  // reduction output index (colour r g b | conic A B C | mean sums x y | opacity) -> slot in the accumulator record's order
   const int writer_val = lane == 1 ? 8 : 4 * (lane >> 5) + (((lane >> 2) & 1) << 1) + ((lane >> 3) & 1);
   const int writer_comp = writer_val < 3 ? GGD_ACC_COLOR + writer_val
                         : (writer_val < 6 ? GGD_ACC_CONIC + (writer_val - 3)
@@ -802,7 +648,7 @@ __global__ __launch_bounds__(256 / PXL) void blend_backward_tile_kernel(
       rec[lane * 3 + 0] = make_float4(0, 0, 0, 0);
       rec[lane * 3 + 1] = make_float4(0, __builtin_huge_valf(), 0, 0);
     }
-    if (wv == 0 && lane < n) { s_id[par][lane] = id_cur; s_op[par][lane] = r1.z; }
+    if (wv == 0 && lane < n) { s_id[par][lane] = id_cur; s_cop[par][lane] = make_float4(r0.z, r0.w, r1.x, r1.z); }
     load_rec(cstart);                                    // next round's records
     load_id(cstart > rg.x ? round_start(cstart) : rg.x); // and the list entries of the round after it
     __builtin_amdgcn_wave_barrier();
@@ -816,58 +662,15 @@ __global__ __launch_bounds__(256 / PXL) void blend_backward_tile_kernel(
         const float dy = a.y - pyf;
         const float nBdy = a.w * dy, hCdy2 = (b.x * dy) * dy;
         const uint32_t pos0 = __float_as_uint(b.w);
-        float dx[PXL], pw[PXL];
-        uint64_t need[PXL], any = 0ull;
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) {
-          dx[k] = a.x - px[k];
-          pw[k] = __builtin_fmaf(__builtin_fmaf(a.z, dx[k], nBdy), dx[k], hCdy2);
-          need[k] = __ballot(pos0 < lastn[k]) & __ballot(pw[k] >= b.y);   // two compares into SGPR pairs + s_and
-          any |= need[k];
-        }
-        if (any == 0ull) continue;
+        const float dx = a.x - pxf;
+        const float pw = __builtin_fmaf(__builtin_fmaf(a.z, dx, nBdy), dx, hCdy2);
+        const uint64_t need = __ballot(pos0 < lastn) & __ballot(pw >= b.y);   // two compares into SGPR pairs + s_and
+        if (need == 0ull) continue;
         const float4 c = grp[jj * 3 + 2];                            // g, b, r, index inside the round
-        const float cA = -2.0f * a.z, cB = -a.w, cC = -2.0f * b.x;   // the conic (exact rescalings of hA, nB, hC)
         const float col[3] = {c.z, c.x, c.y};
-        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sop = 0.0f;   // colour r g b | conic A B C | mean x y ; opacity
-        uint64_t any_live = 0ull;
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) {
-          // exact per-pixel visibility test, then alpha = G = 0 for pixels that do not see the record: every state
-          // update below is then an exact no-op for them (select-free recurrences)
-          const float g0 = blend_exp<EXP_MODE>(pw[k]);
-          const float a0 = fminf(0.99f, b.z * g0);
-          const uint64_t live = need[k] & ~__ballot(pw[k] > 0.0f) & ~__ballot(a0 < ALPHA_FLOOR);
-          any_live |= live;
-          const float G = sel_or_zero(g0, live), alpha = sel_or_zero(a0, live);
-          const float om = 1.0f - alpha;
-          float inv = __builtin_amdgcn_rcpf(om);
-          inv = __builtin_fmaf(inv, __builtin_fmaf(-om, inv, 1.0f), inv);
-          T[k] = T[k] * inv;
-          const float dchannel_dcolor = alpha * T[k];
-          const float oml = 1.0f - la[k];
-          float dL_dalpha = 0.0f;
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            acc[k][ch] = __builtin_fmaf(la[k], lastc[k][ch], oml * acc[k][ch]);
-            asm volatile("v_mov_b32_e32 %0, %1" : "+v"(lastc[k][ch]) : "v"(col[ch]));   // in place (no copy on the culled path)
-            dL_dalpha = __builtin_fmaf(col[ch] - acc[k][ch], gpx[k][ch], dL_dalpha);
-            s[ch] = __builtin_fmaf(dchannel_dcolor, gpx[k][ch], s[ch]);
-          }
-          la[k] = alpha;
-          dL_dalpha = __builtin_fmaf(nTfin[k] * inv, bgdot[k], dL_dalpha * T[k]);
-          const float gdx = G * dx[k], gdy = G * dy;
-          const float ex = __builtin_fmaf(gdy, cB, gdx * cA);   // -dG/d(delta x)
-          const float ey = __builtin_fmaf(gdx, cB, gdy * cC);   // -dG/d(delta y)
-          s[6] = __builtin_fmaf(dL_dalpha, ex, s[6]);
-          s[7] = __builtin_fmaf(dL_dalpha, ey, s[7]);
-          const float wx = gdx * dL_dalpha, wy = gdy * dL_dalpha;
-          s[3] = __builtin_fmaf(wx, dx[k], s[3]);
-          s[4] = __builtin_fmaf(wx, dy, s[4]);
-          s[5] = __builtin_fmaf(wy, dy, s[5]);
-          sop = __builtin_fmaf(G, dL_dalpha, sop);
-        }
-        if (any_live != 0ull) {   // wave-uniform: somebody in this wave saw the Gaussian
+        float s[8], sop;                                             // colour r g b | conic A B C | mean sums x y ; opacity
+        const uint64_t live = bwd_update<EXP_MODE>(st, pw, dx, dy, need, b.z, col, s, sop);
+        if (live != 0ull) {   // wave-uniform: somebody in this wave saw the Gaussian
           const uint32_t ridx = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(c.w));
           touched |= 1ull << ridx;
           const float tot = wave_reduce9_swap(s, sop, 0x2222222222222222ull);
@@ -883,25 +686,27 @@ __global__ __launch_bounds__(256 / PXL) void blend_backward_tile_kernel(
       // accumulator record's order (conic A B C | opacity | mean x y | colour r g b), so consecutive lanes add to
       // consecutive floats of one 48-byte record and the atomics of a record reach L2 as one or two requests
       // instead of nine (a lane per record and one component per instruction was bound by the L2 atomic units).
-      // All waves' sums and the per-record constants (opacity, -1/2, the 0.5 W / 0.5 H of the pixel-to-NDC map) are applied here.
+      // All waves' sums are combined and the per-record constants applied here (bwd_scale).
       uint64_t tw[NW];
 #pragma unroll
       for (int w = 0; w < NW; ++w) tw[w] = (uint64_t)s_touch[par][w][0] | ((uint64_t)s_touch[par][w][1] << 32);
       for (int t = threadIdx.x; t < 64 * 9; t += 64 * NW) {
         const int r = t / 9, slot = t - 9 * r;
         if (r >= n) break;
-        float v = 0.0f;
+        float v = 0.0f, swx = 0.0f, swy = 0.0f;
         bool hany = false;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
           const bool h = (tw[w] >> r) & 1ull;
           hany = hany || h;
-          v += h ? (&s_sum[par][w][0][0])[t] : 0.0f;
+          v += h ? s_sum[par][w][r][slot] : 0.0f;
+          swx += h ? s_sum[par][w][r][GGD_ACC_MEAN2D] : 0.0f;
+          swy += h ? s_sum[par][w][r][GGD_ACC_MEAN2D + 1] : 0.0f;
         }
         if (!hany) continue;
-        const float op = s_op[par][r];
-        const float scale = slot < 3 ? -0.5f * op : (slot == 4 ? -op * ddelx_dx : (slot == 5 ? -op * ddely_dy : 1.0f));
-        atomicAdd(grad_acc + GGD_ACC_FLOATS * (size_t)s_id[par][r] + slot, slot < 3 || slot == 4 || slot == 5 ? scale * v : v);
+        const float4 co = s_cop[par][r];
+        atomicAdd(grad_acc + GGD_ACC_FLOATS * (size_t)s_id[par][r] + slot,
+                  bwd_scale(slot, v, swx, swy, co.x, co.y, co.z, co.w, ddelx_dx, ddely_dy));
       }
     }
     cend = cstart;
@@ -912,22 +717,24 @@ __global__ __launch_bounds__(256 / PXL) void blend_backward_tile_kernel(
 
 // ---- backward blend, quarter form: every 8x8 quarter of a tile is an INDEPENDENT single-wave workgroup --------------------
 // No workgroup barrier and no cross-wave combine: a wave walks the tile's list back to front from ITS OWN last contributor,
-// parks the per-record sums of a round in LDS in processing order (row = 9 sums + the Gaussian's id + its opacity), and
-// flushes them itself -- (record, component) pairs over the lanes, component fastest, so a record's nine atomics form one
-// 36-byte span -- at the top of the NEXT round, before that round's prefetch loads are issued: a wait for the loads then
-// never waits for younger atomics (loads and atomics share one in-order counter).  Compared with the tile form a Gaussian
-// that touches k quarters of a tile costs k coalesced atomic spans instead of one; in exchange the four quarters never wait
-// for each other (the tile form spent 13 % / 28 % of its time in the per-round lock step: cube / shell), and the four
-// quarters of a tile are placed in consecutive dispatch slots of one XCD like the forward's.
+// parks the per-record sums of a round in LDS in processing order (row = 9 sums + the record's slot in the staging area,
+// where its id, opacity and conic still are), and flushes them itself -- (record, component) pairs over the lanes, component
+// fastest, so a record's nine atomics form one 36-byte span -- at the top of the NEXT round, before that round's records
+// overwrite the staging area and before its prefetch loads are issued: a wait for the loads then never waits for younger
+// atomics (loads and atomics share one in-order counter).  Compared with the tile form a Gaussian that touches k quarters of
+// a tile costs k coalesced atomic spans instead of one; in exchange the four quarters never wait for each other (the tile
+// form spent 13 % / 28 % of its time in the per-round lock step: cube / shell), and the four quarters of a tile are placed in
+// consecutive dispatch slots of one XCD like the forward's.
 template <int EXP_MODE, bool CULL>
 __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
     int W, int H, int gx, int gy, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ list,
     const uint32_t* __restrict__ ranges, const float* __restrict__ bg, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
   __shared__ float4 s_rec[64 * 3];
-  // [touched record, in processing order][9 sums | id | opacity] (5888 B of LDS per wave with s_rec: 27 waves per CU); ONE buffer: a round's rows are flushed at the top of the
-  // next round, before that round's first row is written (LDS operations of a wave execute in order)
-  __shared__ float s_sum[64][11];
+  // [touched record, in processing order][9 sums | staging slot] (5632 B of LDS per wave with s_rec); ONE buffer: a round's
+  // rows are flushed at the top of the next round, before that round's first row is written (LDS operations of a wave
+  // execute in order)
+  __shared__ float s_sum[64][10];
   const int lane = threadIdx.x;
   int tile, sub;
   ggd_block_to_tile((int)blockIdx.x, 4, gx, gy, gx * gy, tile, sub);
@@ -939,15 +746,15 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
   const size_t HW = (size_t)H * W;
   const size_t pix0 = (size_t)py * W + px0;
 
-  float T, nTfin, la = 0.0f, bgdot, acc[3] = {0.0f, 0.0f, 0.0f}, lastc[3] = {0.0f, 0.0f, 0.0f}, gpx[3];
+  BwdPixel st;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const float pxf = (float)px0, pyf = (float)py;
   const float tf = in ? final_T[pix0] : 0.0f;
   const uint32_t lastn = in ? n_contrib[pix0] : 0u;
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) gpx[ch] = in ? dL_dpix[ch * HW + pix0] : 0.0f;
-  bgdot = (bg0 * gpx[0] + bg1 * gpx[1]) + bg2 * gpx[2];
-  T = tf; nTfin = -tf;
+  for (int ch = 0; ch < 3; ++ch) { st.gpx[ch] = in ? dL_dpix[ch * HW + pix0] : 0.0f; st.acc[ch] = 0.0f; }
+  st.bgdot = (bg0 * st.gpx[0] + bg1 * st.gpx[1]) + bg2 * st.gpx[2];
+  st.T = tf; st.nTfin = -tf;
   uint32_t maxn = lastn;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) maxn = max(maxn, (uint32_t)__shfl_xor((int)maxn, d, 64));
@@ -958,14 +765,14 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
   const float wx1 = wx0 + 7.0f, wy1 = wy0 + 7.0f;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   // lanes that hold a result of wave_reduce9_swap, and where it goes in the row (accumulator-record order: conic A B C |
-  // opacity | mean x y | colour r g b); lanes 2 and 3 add the record's id and opacity to the same LDS store
+  // opacity | mean sums x y | colour r g b); lane 2 adds the record's staging slot to the same LDS store
   const bool is_writer = (lane & 19) == 0 || lane == 1;
   const int writer_val = lane == 1 ? 8 : 4 * (lane >> 5) + (((lane >> 2) & 1) << 1) + ((lane >> 3) & 1);
   const int writer_comp = writer_val < 3 ? GGD_ACC_COLOR + writer_val
                         : (writer_val < 6 ? GGD_ACC_CONIC + (writer_val - 3)
                         : (writer_val < 8 ? GGD_ACC_MEAN2D + (writer_val - 6) : GGD_ACC_OPACITY));
-  const bool stores = is_writer || lane == 2 || lane == 3;
-  const int store_col = is_writer ? writer_comp : (lane == 2 ? 9 : 10);
+  const bool stores = is_writer || lane == 2;
+  const int store_col = is_writer ? writer_comp : 9;
 
   // staged = the record as loaded with three words replaced in place:
   //   {x, y, hA, nB} {hC, power threshold, opacity, 0-based list position} {g, b, r, Gaussian id}
@@ -1011,18 +818,18 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
       r2.w = __uint_as_float(id_cur);
     }
   };
-  // the flush of one round's parked sums (cnt rows of buffer b)
+  // the flush of one round's parked sums (cnt rows), reading the round's records where they were staged
   auto flush = [&](int cnt) {
     const float* rows = &s_sum[0][0];
     for (int p = lane; p < cnt * 9; p += 64) {
       const int r = p / 9, comp = p - 9 * r;
-      const float v = rows[r * 11 + comp];
-      const uint32_t id = __float_as_uint(rows[r * 11 + 9]);
-      const float op = rows[r * 11 + 10];
-      // d alpha / d G = opacity; d G / d conic = -1/2 G d d^T; the 0.5 W / 0.5 H of the pixel-to-NDC map and the minus sign
-      // of dG/d(delta) -- applied once per (record, component) here instead of per pixel
-      const float scale = comp < 3 ? -0.5f * op : (comp == 4 ? -op * ddelx_dx : (comp == 5 ? -op * ddely_dy : 1.0f));
-      atomicAdd(grad_acc + GGD_ACC_FLOATS * (size_t)id + comp, (comp < 3 || comp == 4 || comp == 5) ? scale * v : v);
+      const float v = rows[r * 10 + comp];
+      const float swx = rows[r * 10 + GGD_ACC_MEAN2D], swy = rows[r * 10 + GGD_ACC_MEAN2D + 1];
+      const int slot = (int)__float_as_uint(rows[r * 10 + 9]);
+      const float4 a = s_rec[slot * 3 + 0], b = s_rec[slot * 3 + 1];
+      const uint32_t id = __float_as_uint(s_rec[slot * 3 + 2].w);
+      atomicAdd(grad_acc + GGD_ACC_FLOATS * (size_t)id + comp,
+                bwd_scale(comp, v, swx, swy, a.z, a.w, b.x, b.z, ddelx_dx, ddely_dy));
     }
   };
 
@@ -1035,6 +842,8 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
     const uint32_t cstart = round_start(cend);
     consume(cend);                                       // the records requested one round ago
     __builtin_amdgcn_wave_barrier();                     // (the previous round's LDS reads are done: in-order per wave)
+    flush(prev_cnt);                                     // the previous round's sums: BEFORE its records are overwritten and
+    __builtin_amdgcn_wave_barrier();                     // before the new loads are issued
     const uint64_t kept = __ballot(keep);
     const int nk = __popcll(kept), n8 = (nk + 7) & ~7;
     if (keep) {  // compacted, order preserved
@@ -1045,7 +854,6 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
       s_rec[lane * 3 + 0] = make_float4(0, 0, 0, 0);
       s_rec[lane * 3 + 1] = make_float4(0, __builtin_huge_valf(), 0, 0);
     }
-    flush(prev_cnt);                                     // the previous round's sums, BEFORE the new loads are issued
     load_rec();                                          // next round's records
     load_id(cstart > rg.x ? round_start(cstart) : rg.x); // and the list entries of the round after it
     __builtin_amdgcn_wave_barrier();
@@ -1067,48 +875,16 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
         const float pw = __builtin_fmaf(__builtin_fmaf(a.z, dx, nBdy), dx, hCdy2);
         const uint64_t need = __ballot(pos0 < lastn) & __ballot(pw >= b.y);
         if (need == 0ull) continue;
-        const float4 c = lds_read4(grp + jj * 3 + 2);                // g, b, r, Gaussian id
-        const float cA = -2.0f * a.z, cB = -a.w, cC = -2.0f * b.x;   // the conic (exact rescalings of hA, nB, hC)
-        const float col[3] = {c.z, c.x, c.y};
-        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sop;                  // colour r g b | conic A B C | mean x y ; opacity
-        // exact per-pixel visibility test, then alpha = G = 0 for pixels that do not see the record: every state update
-        // below is then an exact no-op for them (select-free recurrences)
-        const float g0 = blend_exp<EXP_MODE>(pw);
-        const float a0 = fminf(0.99f, b.z * g0);
-        const uint64_t live = need & ~__ballot(pw > 0.0f) & ~__ballot(a0 < ALPHA_FLOOR);
-        const float G = sel_or_zero(g0, live), alpha = sel_or_zero(a0, live);
-        const float om = 1.0f - alpha;
-        float inv = __builtin_amdgcn_rcpf(om);
-        inv = __builtin_fmaf(inv, __builtin_fmaf(-om, inv, 1.0f), inv);
-        T = T * inv;
-        const float dchannel_dcolor = alpha * T;
-        const float oml = 1.0f - la;
-        float dL_dalpha = 0.0f;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          acc[ch] = __builtin_fmaf(la, lastc[ch], oml * acc[ch]);
-          asm volatile("v_mov_b32_e32 %0, %1" : "+v"(lastc[ch]) : "v"(col[ch]));   // in place (no copy on the culled path)
-          dL_dalpha = __builtin_fmaf(col[ch] - acc[ch], gpx[ch], dL_dalpha);
-          s[ch] = dchannel_dcolor * gpx[ch];
-        }
-        la = alpha;
-        dL_dalpha = __builtin_fmaf(nTfin * inv, bgdot, dL_dalpha * T);
-        const float gdx = G * dx, gdy = G * dy;
-        const float ex = __builtin_fmaf(gdy, cB, gdx * cA);   // -dG/d(delta x)
-        const float ey = __builtin_fmaf(gdx, cB, gdy * cC);   // -dG/d(delta y)
-        s[6] = dL_dalpha * ex;
-        s[7] = dL_dalpha * ey;
-        const float wx = gdx * dL_dalpha, wy = gdy * dL_dalpha;
-        s[3] = wx * dx;
-        s[4] = wx * dy;
-        s[5] = wy * dy;
-        sop = G * dL_dalpha;
+        const float2 c = lds_read2(grp + jj * 3 + 2, 0);             // g, b
+        const float col[3] = {lds_read2(grp + jj * 3 + 2, 2).x, c.x, c.y};
+        float s[8], sop;                                             // colour r g b | conic A B C | mean sums x y ; opacity
+        const uint64_t live = bwd_update<EXP_MODE>(st, pw, dx, dy, need, b.z, col, s, sop);
         if (live != 0ull) {   // wave-uniform: somebody in this wave saw the Gaussian
           const float tot = wave_reduce9_swap(s, sop, 0x2222222222222222ull);
           // writers: lanes 0,4,8,12 | 32,36,40,44 (component from the table above), lane 1 the opacity sum; lane 2 the
-          // Gaussian's id, lane 3 its opacity
-          const float v = is_writer ? tot : (lane == 2 ? c.w : b.z);
-          if (stores) rows[cnt * 11 + store_col] = v;
+          // record's slot in the staging area
+          const float v = is_writer ? tot : __uint_as_float((uint32_t)(j0 + jj));
+          if (stores) rows[cnt * 10 + store_col] = v;
           ++cnt;
         }
       }
@@ -1167,11 +943,11 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
   const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
   const int T = gx * gy;
   int split = ctx->opt[GGD_OPT_BLEND_SPLIT];
-  // 4: four INDEPENDENT 8x8 quarter waves per tile (blend_backward_quarter_kernel); 3: four 8x8 waves per tile in one
-  // workgroup, 2: two 16x8 waves per tile in one workgroup (per-record sums combined in LDS: blend_backward_tile_kernel);
-  // 0: one wave per tile, 4 pixels per lane (blend_backward_kernel).  1 (auto): the quarter form from 2048 tiles (8 waves per
-  // SIMD to draw from: 1 M / 1024^2 cube 375 -> 333 us, shell 744 -> 565 us), the tile form below (with 4 waves per SIMD the
-  // kernel is one wave's serial chain long, and the quarter form's wave flushes its sums alone: 500 k / 512^2 184 vs 206 us)
+  // 4: four INDEPENDENT 8x8 quarter waves per tile (blend_backward_quarter_kernel); any other explicit value: the four
+  // quarter waves of a tile in one workgroup, per-record sums combined in LDS (blend_backward_tile_kernel).  1 (auto): the
+  // quarter form from 2048 tiles (8 waves per SIMD to draw from: 1 M / 1024^2 cube 375 -> 333 us, shell 744 -> 565 us), the
+  // tile form below (with 4 waves per SIMD the kernel is one wave's serial chain long, and the quarter form's wave flushes
+  // its sums alone: 500 k / 512^2 184 vs 206 us)
   if (split == 1) split = T >= 2048 ? 4 : 3;
   if (split == 4) {
 #define GGD_LAUNCH_BQ(EM, CU)                                                                                             \
@@ -1186,34 +962,15 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
     GGD_HIP(hipGetLastError());
     return GGD_OK;
   }
-  if (split != 0) {
 #define GGD_LAUNCH_BT(EM, CU)                                                                                             \
-    do {                                                                                                                  \
-      if (split != 2)                                                                                                     \
-        hipLaunchKernelGGL((blend_backward_tile_kernel<EM, CU, 1>), dim3(T), dim3(256), 0, s, prm.width, prm.height, gx,  \
-                           gy, splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc);                       \
-      else                                                                                                                \
-        hipLaunchKernelGGL((blend_backward_tile_kernel<EM, CU, 2>), dim3(T), dim3(128), 0, s, prm.width, prm.height, gx,  \
-                           gy, splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc);                       \
-    } while (0)
-    if (cull) {
-      if (em == 0) GGD_LAUNCH_BT(0, true); else if (em == 1) GGD_LAUNCH_BT(1, true); else GGD_LAUNCH_BT(2, true);
-    } else {
-      if (em == 0) GGD_LAUNCH_BT(0, false); else if (em == 1) GGD_LAUNCH_BT(1, false); else GGD_LAUNCH_BT(2, false);
-    }
-#undef GGD_LAUNCH_BT
-    GGD_HIP(hipGetLastError());
-    return GGD_OK;
-  }
-#define GGD_LAUNCH_BWD(EM, CU)                                                                                          \
-  hipLaunchKernelGGL((blend_backward_kernel<EM, CU, 4>), dim3(T), dim3(64), 0, s, prm.width, prm.height, gx, T, splat,  \
-                     list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc)
+  hipLaunchKernelGGL((blend_backward_tile_kernel<EM, CU>), dim3(T), dim3(256), 0, s, prm.width, prm.height, gx,           \
+                     gy, splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc)
   if (cull) {
-    if (em == 0) GGD_LAUNCH_BWD(0, true); else if (em == 1) GGD_LAUNCH_BWD(1, true); else GGD_LAUNCH_BWD(2, true);
+    if (em == 0) GGD_LAUNCH_BT(0, true); else if (em == 1) GGD_LAUNCH_BT(1, true); else GGD_LAUNCH_BT(2, true);
   } else {
-    if (em == 0) GGD_LAUNCH_BWD(0, false); else if (em == 1) GGD_LAUNCH_BWD(1, false); else GGD_LAUNCH_BWD(2, false);
+    if (em == 0) GGD_LAUNCH_BT(0, false); else if (em == 1) GGD_LAUNCH_BT(1, false); else GGD_LAUNCH_BT(2, false);
   }
-#undef GGD_LAUNCH_BWD
+#undef GGD_LAUNCH_BT
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }
