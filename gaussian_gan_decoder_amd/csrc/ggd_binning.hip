@@ -10,7 +10,7 @@
 //     one kernel per pass -- per-tile ranking with wave64 ballot matching (rank inside a wave = popcount of lower
 //     peer lanes), decoupled look-back over the earlier tiles' digit counts, scatter.  Two instantiations: 64-bit
 //     (tile | depth bits) keys over [0, 32+msb(T)) for the duplicateWithKeys path, and 32-bit depth keys with
-//     identity values for the tile-binning paths (ggd_tilebin.hip, ggd_rowbin.hip), where culled Gaussians are
+//     identity values for the tile-binning paths (ggd_rowbin.hip), where culled Gaussians are
 //     dropped in pass 0 and constant-digit passes degrade to copies.  Keys embed raw fp32 depth bits, so the sorted
 //     order (ties included) is identical to a stable sort of the emission order.
 #include "ggd_common.h"

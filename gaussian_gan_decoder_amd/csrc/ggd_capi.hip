@@ -112,6 +112,7 @@ extern "C" ggd_ctx* ggd_create(int device) {
   if (const char* e = getenv("GGD_BINNING")) { const int v = atoi(e); if (v >= 0 && v <= 3) ctx->opt[GGD_OPT_BINNING] = v; }
   if (const char* e = getenv("GGD_BLEND_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 4) ctx->opt[GGD_OPT_BLEND_SPLIT] = v; }
   if (const char* e = getenv("GGD_BLEND_CULL")) ctx->opt[GGD_OPT_BLEND_CULL] = atoi(e) != 0;
+  if (const char* e = getenv("GGD_BLEND_PERSIST")) ctx->opt[GGD_OPT_BLEND_PERSIST] = atoi(e) != 0;
   int prev = 0;
   (void)hipGetDevice(&prev);
   bool ok = hipSetDevice(device) == hipSuccess &&
@@ -150,6 +151,7 @@ extern "C" void ggd_destroy(ggd_ctx* ctx) {
   if (ctx->d_words) (void)hipFree(ctx->d_words);
   if (ctx->h_words) (void)hipHostFree(ctx->h_words);
   if (ctx->sortctl) (void)hipFree(ctx->sortctl);
+  if (ctx->blend_tickets) (void)hipFree(ctx->blend_tickets);
   if (ctx->scan_sums) (void)hipFree(ctx->scan_sums);
   if (ctx->stats_buf) (void)hipFree(ctx->stats_buf);
   if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);
@@ -163,7 +165,7 @@ extern "C" const char* ggd_last_error(ggd_ctx* ctx) { return ctx ? ctx->err.c_st
 
 extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
   if (!ctx) return GGD_E_INVALID;
-  static const int kMax[GGD_OPT_COUNT] = {2, 1, 3, 4};
+  static const int kMax[GGD_OPT_COUNT] = {2, 1, 3, 4, 1};
   if (option < 0 || option >= GGD_OPT_COUNT || value < 0 || value > kMax[option])
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_set_option: unknown option or value");
   ctx->opt[option] = value;
@@ -407,12 +409,11 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
   const int nbits = ggd_sort_bits(prm->width, prm->height);
 
   const int bmode = ctx->opt[GGD_OPT_BINNING];
-  // binning path: 0 = duplicate + radix sort; 2 = single-level tile binning; 3 = two-level row/column binning;
-  // 1 = auto: row binning when the grid is <= 255 x 255 tiles (and R is past its fixed costs), else as before
+  // binning path: 0 = duplicate + radix sort; 3 (2: alias) = two-level row / column binning; 1 = auto: row binning when the
+  // grid is <= 255 x 255 tiles (and R is past its fixed costs), else the sort
   const bool rowbin_ok = !prm->debug && ggd_rowbin_supported(prm->width, prm->height);
-  const bool rowbin = rowbin_ok && (bmode == 3 || (bmode == 1 && R >= GGD_ROWBIN_MIN_R));
-  const bool tilebin = rowbin || ((bmode == 2 || bmode == 3 || (bmode == 1 && R >= (1 << 20))) && !prm->debug &&
-                                  ggd_tilebin_supported(T));
+  const bool rowbin = rowbin_ok && (bmode == 2 || bmode == 3 || (bmode == 1 && R >= GGD_ROWBIN_MIN_R));
+  const bool tilebin = rowbin;
   if (speculative && !tilebin) return ggd_fail(ctx, GGD_E_INVALID, "speculative render needs the tile-binning path");
   const uint32_t capacity = R > 0xffffffffll ? 0xffffffffu : (uint32_t)R;
   if (R > 0 && tilebin) {
@@ -420,7 +421,7 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
     const uint32_t* depth_keys = reinterpret_cast<const uint32_t*>(gb + gv.depth_keys);
     const size_t pairs = ggd_align((size_t)prm->P * sizeof(uint32_t));
     const size_t sort_tmp = ggd_sort32_tmp_bytes(prm->P);
-    const size_t bin_tmp = rowbin ? ggd_rowbin_tmp_bytes(prm->P, capacity, prm->width, prm->height) : ggd_tilebin_tmp_bytes(prm->P, T);
+    const size_t bin_tmp = ggd_rowbin_tmp_bytes(prm->P, capacity, prm->width, prm->height);
     rc = ggd_reserve_scratch(ctx, 4 * pairs + sort_tmp + bin_tmp, s);
     if (rc != GGD_OK) return rc;
     char* sc = static_cast<char*>(ctx->scratch);
@@ -459,9 +460,8 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
       // the depth sort dropped the culled Gaussians (key 0xFFFFFFFF) and left the number of kept ones on the device
       const uint32_t* n_vis = ggd_sort32_nvalid_ptr(clean_ctl ? static_cast<const void*>(clean_ctl) : tmp);
       const void* ctl = clean_ctl ? static_cast<const void*>(clean_ctl) : tmp;
-      rc = rowbin ? ggd_launch_rowbin(ctx, s, *prm, rect, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp, vb,
-                                      ggd_sort32_flat_ptr(ctl), riding ? &pg : nullptr)
-                  : ggd_launch_tilebin(ctx, s, *prm, rect, tiles, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp);
+      rc = ggd_launch_rowbin(ctx, s, *prm, rect, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp, vb,
+                             ggd_sort32_flat_ptr(ctl), riding ? &pg : nullptr);
       if (rc != GGD_OK) return rc;
     }
   } else {
@@ -516,11 +516,9 @@ extern "C" int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* 
 
 extern "C" int ggd_forward_can_speculate(ggd_ctx* ctx, const ggd_params* prm, int64_t capacity) {
   if (!ctx || !prm || prm->debug || prm->P <= 0) return 0;
-  const int T = ((prm->width + 15) / 16) * ((prm->height + 15) / 16);
   const int bmode = ctx->opt[GGD_OPT_BINNING];
-  if (ggd_rowbin_supported(prm->width, prm->height) && (bmode == 3 || (bmode == 1 && capacity >= GGD_ROWBIN_MIN_R)))
-    return 1;
-  return ((bmode == 2 || bmode == 3 || (bmode == 1 && capacity >= (1 << 20))) && ggd_tilebin_supported(T)) ? 1 : 0;
+  return (ggd_rowbin_supported(prm->width, prm->height) &&
+          (bmode == 2 || bmode == 3 || (bmode == 1 && capacity >= GGD_ROWBIN_MIN_R))) ? 1 : 0;
 }
 
 extern "C" int ggd_forward(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D, const float* shs,

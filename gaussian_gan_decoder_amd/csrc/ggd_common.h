@@ -20,8 +20,7 @@ enum {
   ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_COUNT
 };
 
-enum { GGD_ATTR_MLP_FWD = 1, GGD_ATTR_MLP_BWD = 2, GGD_ATTR_MLP_WGRAD = 4, GGD_ATTR_TILEBIN = 8, GGD_ATTR_TRIPLANE32 = 16,
-       GGD_ATTR_TRIPLANE16 = 32, GGD_ATTR_MLP_HL = 64 };
+enum { GGD_ATTR_MLP_FWD = 1, GGD_ATTR_MLP_BWD = 2, GGD_ATTR_MLP_WGRAD = 4, GGD_ATTR_MLP_HL = 64 };
 
 // layout of the debug statistics buffer of the forward blend (ggd_blend_stats / ggd_blend_timeline)
 constexpr int GGD_STATS_MODE = 9;            // word: 0 = counters (atomics), 1 = per-wave timeline slots
@@ -41,12 +40,14 @@ struct ggd_ctx {
   uint32_t* scan_sums = nullptr;    // block sums of a scan that rides on the depth sort (own allocation, grow-only)
   int scan_sums_cap = 0;
   bool scan_deferred = false;       // geometry_enqueue left the scan to the sort launches of the same call
+  uint32_t* blend_tickets = nullptr; // ticket counters of the persistent forward blend (allocated on first use)
+  int persist_grid = 0;             // workgroups of the persistent forward blend (occupancy x CUs), 0 = not queried yet
   uint32_t r_tag = 0;               // sequence number of the single-call forward whose num_rendered the host is waiting for
   bool r_pending = false;           // the host waits for the tagged word (h_words[2..3]), not for the end of the frame
   void* dbg_keys = nullptr;     // debug copy of the unsorted list
   void* dbg_vals = nullptr;
   size_t dbg_cap = 0;
-  int opt[GGD_OPT_COUNT] = {2, 1, 1, 1};  // exp: compensated 2^x (1-ulp class like ocml expf, ~8 % faster blend)
+  int opt[GGD_OPT_COUNT] = {2, 1, 1, 1, 0};  // exp: compensated 2^x (1-ulp class like ocml expf, ~8 % faster blend)
   unsigned long long* blend_stats = nullptr;  // debug: device counters filled by the forward blend when non-null
   unsigned long long* stats_buf = nullptr;    // its storage: [0..4] counters, [GGD_STATS_MODE] 1 = per-wave timeline, slots from GGD_STATS_HEAD
   bool profiling = false;
@@ -147,11 +148,6 @@ int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const 
                       const ggd_scan_piggy* apply = nullptr);   // apply: step 3 of a riding scan, as appended workgroups of the
                                                                  // last (longest) binning launch
                       // *use_alt != 0 (device): the depth order is in order_alt (see ggd_launch_sort32_iota)
-bool ggd_tilebin_supported(int T);
-size_t ggd_tilebin_tmp_bytes(int P, int T);
-int ggd_launch_tilebin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect,
-                       const uint32_t* tiles_touched, const uint32_t* order, const uint32_t* n_vis_ptr,
-                       uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp, size_t tmp_bytes);
 int ggd_launch_ranges(ggd_ctx* ctx, hipStream_t s, const uint64_t* keys, int64_t n, uint32_t* ranges, int T);
 int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
                      const uint32_t* list, const uint32_t* ranges, uint32_t capacity, float* out_color, float* final_T,

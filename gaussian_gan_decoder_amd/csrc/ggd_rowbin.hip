@@ -1,7 +1,7 @@
 // ggd_rowbin.hip -- two-level stable tile binning (GGD_OPT_BINNING = 3 / auto): the kernels below for tile grids up to 64 x 64,
 // ggd_rowbin_wide.inc (same algorithm, bins spread over lane groups) for grids up to 255 x 255.
 //
-// Same contract as ggd_tilebin.hip (stages a6-a8 as a RESULT: per tile, the Gaussians whose rect covers it in
+// Contract (stages a6-a8 as a RESULT: per tile, the Gaussians whose rect covers it in
 // (depth bits, index) order, plus ranges), from the depth-ordered Gaussians.  The single-level pass there pays O(T) LDS
 // work per 1024 Gaussians and writes one lone 4-byte store per (block, tile).  A tile rect is a product of two
 // intervals, so the expansion is split into two 1-D counting sorts with <= 64 bins each -- one bin per LANE:

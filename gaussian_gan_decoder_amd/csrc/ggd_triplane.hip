@@ -11,9 +11,6 @@
 // line): lane = channel, 64/C points per wave; every texel access is one coalesced line read, and the backward's
 // scatter-add is one line-wide group of float atomics per texel (torch's NCHW grid_sampler_2d_backward issues one
 // scattered atomic per (point, channel): 9.6 ms per 5e5 points measured on MI355X; this kernel is HBM/L2 bound).
-#include <cstdlib>
-#include <cstring>
-
 #include "ggd_common.h"
 
 namespace {
@@ -166,229 +163,6 @@ int launch(ggd_ctx* ctx, hipStream_t s, const float* planes_cl, float* dplanes_c
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }
-
-// ------------------------------------------------------------------------------------------------------------------
-// Binned backward.  The plain scatter-add above is bound by the L2 atomic units (~2.3e11 lane-atomics/s measured): a
-// training scene puts 5e5 surface points on ~2e4 texels per plane, 192 M float atomics per call.  Here the (point,
-// plane) items are first binned (unordered counting sort) by the 16x16-texel tile of their top-left tap; a workgroup
-// then accumulates one chunk of one bin into a (16+1)^2 x C tile in LDS (ds_add_f32: ~40x the L2 atomic rate) and
-// flushes the tile with one global atomic per touched texel-channel.  (LDS float ATOMICS turned out to run at about one
-// lane per clock per CU on gfx950 -- slower than the L2 path -- so every WAVE owns a private tile and does plain
-// read-add-write: the four taps of one point go to four distinct addresses, lane groups take different taps.)
-constexpr int TPB_TS = 8;          // texels per tile side (the LDS tile has one more row / column for the +1 taps)
-constexpr int TPB_CHUNK = 256;     // items per accumulation wave
-constexpr int TPB_MAX_BINS = 3 * 65 * 65;   // planes up to 512 x 512
-constexpr int TPB_DEPTH = 16;      // gradient rows in flight per wave
-
-struct TpGrid { int ntx, nty, nbins; };
-__host__ __device__ __forceinline__ TpGrid tp_grid(int H, int W) {
-  TpGrid g; g.ntx = W / TPB_TS + 1; g.nty = H / TPB_TS + 1; g.nbins = 3 * g.ntx * g.nty; return g;
-}
-
-// bin of (point, plane) or -1 when all four taps are outside the plane
-__device__ __forceinline__ int tp_bin(int p, float x, float y, float z, int H, int W, const TpGrid& tg) {
-  float u, v;
-  plane_uv(p, x, y, z, u, v);
-  const float ix = ((u + 1.0f) * (float)W - 1.0f) * 0.5f, iy = ((v + 1.0f) * (float)H - 1.0f) * 0.5f;
-  const float fx = floorf(ix), fy = floorf(iy);
-  if (!(fx >= -1.0f && fx <= (float)(W - 1) && fy >= -1.0f && fy <= (float)(H - 1))) return -1;
-  const int tx = ((int)fx + 1) / TPB_TS, ty = ((int)fy + 1) / TPB_TS;
-  return (p * tg.nty + ty) * tg.ntx + tx;
-}
-
-// pass 1 (SCATTER = false): counts[bin] += ...;  pass 2 (SCATTER = true): items[cursor[bin]++] = point
-template <bool SCATTER>
-__global__ __launch_bounds__(256) void tpb_bin_kernel(const float* __restrict__ pos, int N, float scale, int H, int W,
-                                                      uint32_t* __restrict__ counts_or_cursor, uint32_t* __restrict__ items) {
-  extern __shared__ uint32_t s_hist[];   // [nbins] local counts, then (scatter) the reserved global base
-  const TpGrid tg = tp_grid(H, W);
-  for (int b = threadIdx.x; b < tg.nbins; b += 256) s_hist[b] = 0;
-  __syncthreads();
-  int bin[4][3];
-  uint32_t slot[4][3];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int64_t n = (int64_t)blockIdx.x * 1024 + q * 256 + threadIdx.x;
-    float x = 0, y = 0, z = 0;
-    if (n < N) { x = scale * pos[3 * n]; y = scale * pos[3 * n + 1]; z = scale * pos[3 * n + 2]; }
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      bin[q][p] = n < N ? tp_bin(p, x, y, z, H, W, tg) : -1;
-      slot[q][p] = 0;
-      if (bin[q][p] >= 0) slot[q][p] = atomicAdd(&s_hist[bin[q][p]], 1u);
-    }
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < tg.nbins; b += 256) {
-    const uint32_t c = s_hist[b];
-    if (c) {
-      const uint32_t base = atomicAdd(&counts_or_cursor[b], c);
-      if (SCATTER) s_hist[b] = base;
-    }
-  }
-  if (!SCATTER) return;
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int64_t n = (int64_t)blockIdx.x * 1024 + q * 256 + threadIdx.x;
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-      if (bin[q][p] >= 0) items[s_hist[bin[q][p]] + slot[q][p]] = (uint32_t)n;
-  }
-}
-
-// tab: [0 .. nbins] bin starts, [nbins+1 .. 2 nbins+1] first accumulation block of every bin (+ total), then cursors
-__global__ __launch_bounds__(1024) void tpb_scan_kernel(const uint32_t* __restrict__ counts, int nbins,
-                                                        uint32_t* __restrict__ tab) {
-  __shared__ uint32_t s_part[16], s_part2[16];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  uint32_t carry = 0, carry2 = 0;
-  for (int b0 = 0; b0 < nbins; b0 += 1024) {
-    const int b = b0 + tid;
-    const uint32_t c = b < nbins ? counts[b] : 0u;
-    const uint32_t k = (c + TPB_CHUNK - 1) / TPB_CHUNK;
-    uint32_t inc = c, inc2 = k;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = __shfl_up(inc, d, 64), o2 = __shfl_up(inc2, d, 64);
-      if (lane >= d) { inc += o; inc2 += o2; }
-    }
-    if (lane == 63) { s_part[wv] = inc; s_part2[wv] = inc2; }
-    __syncthreads();
-    uint32_t base = 0, base2 = 0, tot = 0, tot2 = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      const uint32_t a = s_part[w], a2 = s_part2[w];
-      if (w < wv) { base += a; base2 += a2; }
-      tot += a; tot2 += a2;
-    }
-    if (b < nbins) {
-      tab[b] = carry + base + inc - c;
-      tab[nbins + 1 + b] = carry2 + base2 + inc2 - k;
-      tab[2 * nbins + 2 + b] = carry + base + inc - c;   // scatter cursor
-    }
-    carry += tot; carry2 += tot2;
-    __syncthreads();
-  }
-  if (tid == 0) { tab[nbins] = carry; tab[2 * nbins + 1] = carry2; }
-}
-
-template <int C>
-__global__ __launch_bounds__(256) void tpb_accumulate_kernel(const float* __restrict__ pos, const uint32_t* __restrict__ items,
-                                                             const uint32_t* __restrict__ tab, int H, int W, float scale,
-                                                             const float* __restrict__ dout,
-                                                             float* __restrict__ dplanes_cl) {
-  extern __shared__ float s_tiles[];   // [4 waves][(TS+1)][(TS+1)][C]
-  constexpr int TW = TPB_TS + 1;
-  constexpr int GROUPS = 64 / C;       // lane groups of C channels; each takes 4 / GROUPS of the point's taps
-  constexpr int TAPS = 4 / GROUPS;
-  static_assert(GROUPS == 2 || GROUPS == 4, "C must be 32 or 16");
-  const TpGrid tg = tp_grid(H, W);
-  const int nb = tg.nbins;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t work = blockIdx.x * 4 + wv;       // one (bin, chunk) per wave
-  if (work >= tab[2 * nb + 1]) return;
-  int bin = 0;
-  for (int step = 8192; step >= 1; step >>= 1)
-    if (bin + step <= nb && tab[nb + 1 + bin + step] <= work) bin += step;   // largest bin with first chunk <= work
-  // (empty bins share their first-chunk index with the next bin: the search lands on the LAST of equal entries)
-  const uint32_t chunk = work - tab[nb + 1 + bin];
-  const uint32_t ibeg = tab[bin] + chunk * TPB_CHUNK, iend = min(tab[bin + 1], ibeg + TPB_CHUNK);
-  const int p = bin / (tg.ntx * tg.nty), ty = (bin / tg.ntx) % tg.nty, tx = bin % tg.ntx;
-  const int ox = tx * TPB_TS - 1, oy = ty * TPB_TS - 1;   // texel of LDS tile entry (0, 0)
-  float* tile = s_tiles + (size_t)wv * TW * TW * C;
-  for (int i = lane; i < TW * TW * C; i += 64) tile[i] = 0.0f;
-  __builtin_amdgcn_wave_barrier();
-  const int c = lane % C, grp = lane / C;
-  // 64 items per batch: lane j fetches item j and computes ITS tile offset and bilinear fractions once; the wave then
-  // walks the batch with scalar broadcasts (v_readlane), TPB_DEPTH items at a time so that as many gradient-row loads are in flight.
-  for (uint32_t b0 = ibeg; b0 < iend; b0 += 64) {
-    const uint32_t i = b0 + (uint32_t)lane;
-    uint32_t n_l = 0;
-    int off_l = 0;
-    float ax_l = 0.0f, ay_l = 0.0f;
-    if (i < iend) {
-      n_l = items[i];
-      const float x = scale * pos[3 * (size_t)n_l], y = scale * pos[3 * (size_t)n_l + 1], z = scale * pos[3 * (size_t)n_l + 2];
-      float u, v;
-      plane_uv(p, x, y, z, u, v);
-      const float ix = ((u + 1.0f) * (float)W - 1.0f) * 0.5f, iy = ((v + 1.0f) * (float)H - 1.0f) * 0.5f;
-      const float fx = floorf(ix), fy = floorf(iy);
-      ax_l = ix - fx; ay_l = iy - fy;
-      off_l = (((int)fy - oy) * TW + ((int)fx - ox)) * C;   // (ly, lx) in 0 .. TS-1 by construction of the bin
-    }
-    const int cnt = (int)min(64u, iend - b0);
-    for (int j0 = 0; j0 < cnt; j0 += TPB_DEPTH) {
-      float g[TPB_DEPTH];
-#pragma unroll
-      for (int k = 0; k < TPB_DEPTH; ++k) {
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)n_l, (j0 + k) & 63);
-        g[k] = (j0 + k < cnt) ? dout[(size_t)n * C + c] * (1.0f / 3.0f) : 0.0f;
-      }
-#pragma unroll
-      for (int k = 0; k < TPB_DEPTH; ++k) {
-        const int jj = (j0 + k) & 63;
-        const int off = __builtin_amdgcn_readlane(off_l, jj);
-        const float ax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ax_l), jj));
-        const float ay = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ay_l), jj));
-        float* t0 = tile + off + c;
-#pragma unroll
-        for (int q = 0; q < TAPS; ++q) {
-          const int tap = grp * TAPS + q;             // 0: (x0,y0) 1: (x1,y0) 2: (x0,y1) 3: (x1,y1)
-          const float wx = (tap & 1) ? ax : 1.0f - ax, wy = (tap & 2) ? ay : 1.0f - ay;
-          float* t = t0 + ((tap & 1) ? C : 0) + ((tap & 2) ? TW * C : 0);
-          *t += wx * wy * g[k];                       // private tile, distinct addresses within the wave; g = 0 pads
-        }
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  float* plane = dplanes_cl + (size_t)p * H * W * C;
-  for (int i = lane; i < TW * TW * C; i += 64) {
-    const float val = tile[i];
-    if (val != 0.0f) {
-      const int cc = i % C, lx = (i / C) % TW, ly = i / (C * TW);
-      const int gx = ox + lx, gy = oy + ly;
-      if (gx >= 0 && gx < W && gy >= 0 && gy < H) atomicAdd(plane + ((size_t)gy * W + gx) * C + cc, val);
-    }
-  }
-}
-
-size_t tpb_tmp_bytes(int N, int H, int W) {
-  const TpGrid tg = tp_grid(H, W);
-  return ggd_align((size_t)tg.nbins * 4) + ggd_align((size_t)(3 * tg.nbins + 4) * 4) + ggd_align((size_t)3 * N * 4);
-}
-
-template <int C>
-int launch_binned_backward(ggd_ctx* ctx, hipStream_t s, int H, int W, const float* pos, int N, float box_warp,
-                           const float* dout, float* dplanes_cl, void* tmp) {
-  const TpGrid tg = tp_grid(H, W);
-  const float scale = 2.0f / box_warp;
-  char* p = static_cast<char*>(tmp);
-  uint32_t* counts = reinterpret_cast<uint32_t*>(p); p += ggd_align((size_t)tg.nbins * 4);
-  uint32_t* tab = reinterpret_cast<uint32_t*>(p); p += ggd_align((size_t)(3 * tg.nbins + 4) * 4);
-  uint32_t* items = reinterpret_cast<uint32_t*>(p);
-  GGD_HIP(hipMemsetAsync(counts, 0, (size_t)tg.nbins * 4, s));
-  const int nblk = (N + 1023) / 1024;
-  const size_t hist_lds = (size_t)tg.nbins * 4;
-  hipLaunchKernelGGL((tpb_bin_kernel<false>), dim3(nblk), dim3(256), hist_lds, s, pos, N, scale, H, W, counts, items);
-  hipLaunchKernelGGL(tpb_scan_kernel, dim3(1), dim3(1024), 0, s, counts, tg.nbins, tab);
-  hipLaunchKernelGGL((tpb_bin_kernel<true>), dim3(nblk), dim3(256), hist_lds, s, pos, N, scale, H, W,
-                     tab + 2 * tg.nbins + 2, items);
-  const unsigned acc_blocks = (unsigned)(((3 * (size_t)N + TPB_CHUNK - 1) / TPB_CHUNK + tg.nbins + 3) / 4);
-  const size_t tile_lds = (size_t)4 * (TPB_TS + 1) * (TPB_TS + 1) * C * sizeof(float);
-  constexpr uint32_t kBit = C == 32 ? GGD_ATTR_TRIPLANE32 : GGD_ATTR_TRIPLANE16;
-  if (!(ctx->attr_mask & kBit)) {
-    GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tpb_accumulate_kernel<C>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
-    ctx->attr_mask |= kBit;
-  }
-  hipLaunchKernelGGL((tpb_accumulate_kernel<C>), dim3(acc_blocks), dim3(256), tile_lds, s, pos, items, tab, H, W, scale,
-                     dout, dplanes_cl);
-  GGD_HIP(hipGetLastError());
-  return GGD_OK;
-}
-
 
 // ------------------------------------------------------------------------------------------------------------------
 // Sorted-run backward (tri-planes AND tri-grids).  A training scene puts 5e5 surface points on a few 1e4 cells per plane:
@@ -599,16 +373,6 @@ int sorted_backward(ggd_ctx* ctx, hipStream_t s, int C, int D, int H, int W, int
   }
 }
 
-// debug / A-B switch, read once: GGD_PLANES_BWD = "tile" (LDS-tile binning, tri-planes only) | "atomic" | unset (sorted runs)
-int planes_bwd_mode() {
-  static const int mode = [] {
-    const char* e = getenv("GGD_PLANES_BWD");
-    if (!e) return 0;
-    return !strcmp(e, "tile") ? 1 : !strcmp(e, "atomic") ? 2 : 0;
-  }();
-  return mode;
-}
-
 }  // namespace
 
 extern "C" int ggd_planes_gather(ggd_ctx* ctx, void* stream, const float* grids_cl, int32_t C, int32_t D, int32_t H,
@@ -635,19 +399,8 @@ extern "C" int ggd_planes_scatter(ggd_ctx* ctx, void* stream, int32_t C, int32_t
   if (!accumulate) GGD_HIP(hipMemsetAsync(dgrids_cl, 0, (size_t)3 * Dd * H * W * C * sizeof(float), s));
   if (N <= 0) return GGD_OK;
   if (!pos || !dout || box_warp == 0.0f) return ggd_fail(ctx, GGD_E_INVALID, "ggd_planes_scatter: bad argument");
-  const int mode = planes_bwd_mode();
   // many points per cell: sort the (point, plane) items by cell and sum runs in registers; few: plain scatter-add
-  if (mode == 0 && sr_supported(C, D, H, W, N)) return sorted_backward(ctx, s, C, D, H, W, axes, pos, N, box_warp, dout, mod, dgrids_cl);
-  if (mode == 1 && D == 0 && !mod) {
-    const TpGrid tg = tp_grid(H, W);
-    if ((C == 32 || C == 16) && tg.nbins <= TPB_MAX_BINS && (int64_t)N * 3 >= 8 * (int64_t)H * W) {
-      const size_t need = tpb_tmp_bytes(N, H, W);
-      int rc = ggd_reserve_scratch(ctx, need, s);
-      if (rc != GGD_OK) return rc;
-      return C == 32 ? launch_binned_backward<32>(ctx, s, H, W, pos, N, box_warp, dout, dgrids_cl, ctx->scratch)
-                     : launch_binned_backward<16>(ctx, s, H, W, pos, N, box_warp, dout, dgrids_cl, ctx->scratch);
-    }
-  }
+  if (sr_supported(C, D, H, W, N)) return sorted_backward(ctx, s, C, D, H, W, axes, pos, N, box_warp, dout, mod, dgrids_cl);
   if (D == 0) return launch<true>(ctx, s, nullptr, dgrids_cl, C, H, W, pos, N, box_warp, dout, nullptr, mod);
   return launch_trigrid<true>(ctx, s, nullptr, dgrids_cl, C, D, H, W, axes, pos, N, box_warp, dout, nullptr, mod);
 }

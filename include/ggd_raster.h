@@ -199,16 +199,19 @@ enum {
   GGD_OPT_BLEND_CULL = 1, /* 1 (default) = skip records whose alpha cannot reach 1/255 anywhere in the tile */
   GGD_OPT_BINNING = 2,    /* how the per-tile sorted lists are built (results are identical):
                              0 = duplicateWithKeys + 64-bit (tile|depth) radix sort + identifyTileRanges,
-                             2 = depth-sort the Gaussians once, then ONE stable tile-binning pass,
-                             3 = depth-sort, then TWO 1-D stable binning passes (tile rows, then columns; grids up
-                                 to 255 x 255 tiles = 4080 x 4080 pixels, falls back to 2 / 0 beyond),
-                             1 (default) = auto: 3 wherever it applies; beyond it 2 from 2^20 instances (<= 8192 tiles), else 0.
-                             debug=1 (key taps) or a tile grid beyond the LDS budget always uses 0 */
-  GGD_OPT_BLEND_SPLIT = 3, /* blend kernels: 0 = one wave per 16x16 tile (4 px/lane), 2 = two waves per tile (16x8
-                             halves, 2 px/lane), 3 = four waves per tile (8x8 quarters, 1 px/lane; backward: the four in one
-                             workgroup, per-record sums combined in LDS), 4 = backward: four independent 8x8 quarter waves
-                             per tile (forward as 3), 1 (default) = auto (the measured best per kernel).
-                             Forward results are identical; backward sums differ only in their fp32 summation order. */
+                             3 = depth-sort the Gaussians once, then TWO 1-D stable binning passes (tile rows, then
+                                 columns; grids up to 255 x 255 tiles = 4080 x 4080 pixels, falls back to 0 beyond),
+                             2 = alias of 3 (the single-level tile binning it used to select was removed: slower than 3
+                                 on every grid 3 supports),
+                             1 (default) = auto: 3 wherever it applies, else 0.
+                             debug=1 (key taps) always uses 0 */
+  GGD_OPT_BLEND_SPLIT = 3, /* backward blend (the forward always runs four 8x8 quarter waves per tile, one pixel per
+                             lane): 3 = the four quarter waves of a tile in one workgroup, per-record sums combined in LDS;
+                             4 = four independent quarter waves per tile; 1 (default) = auto (4 from 2048 tiles, else 3);
+                             0, 2 = aliases of 3 (the one-wave and two-wave forms they selected were removed).  Backward sums
+                             differ only in their fp32 summation order. */
+  GGD_OPT_BLEND_PERSIST = 4, /* forward blend: 0 (default) = one workgroup per (tile, quarter); 1 = as many workgroups as
+                             the device holds, each drawing (tile, quarter) tickets.  Images are identical. */
   GGD_OPT_COUNT
 };
 int ggd_set_option(ggd_ctx* ctx, int option, int value);

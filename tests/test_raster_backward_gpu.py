@@ -67,12 +67,12 @@ def test_backward_matches_oracle(native_lib, case):
         assert (nb["dL_dsh"].reshape(d["P"], -1, 3)[:, used:] == 0).all()   # coefficients above the active degree
 
 
-@pytest.mark.parametrize("split", [0, 2, 3, 4])
+@pytest.mark.parametrize("split", [3, 4])
 @pytest.mark.parametrize("case", [dict(P=20000, size=256, kind="shell", lsm=-5.5), dict(P=4096, size=100, lsm=-5.0, width=100, height=52)],
                          ids=_ids)
 def test_backward_kernel_forms_match_oracle(native_lib, case, split):
-    """Every form of the backward blend (GGD_OPT_BLEND_SPLIT: one wave per tile / two 16x8 waves / four 8x8 waves in one
-    workgroup) against the same reference and budget; the default (auto) is what the other tests run."""
+    """Both forms of the backward blend (GGD_OPT_BLEND_SPLIT: the four 8x8 quarter waves of a tile in one workgroup /
+    four independent quarter waves) against the same reference and budget; the default (auto) is what the other tests run."""
     import torch as _t
     from gaussian_gan_decoder_amd import _capi
     cx = _capi.context_for(_t.device("cuda:0"))
