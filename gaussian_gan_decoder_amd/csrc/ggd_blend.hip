@@ -437,7 +437,12 @@ all_done:
 }
 
 // One 8x8 quarter per single-wave workgroup (the launch has 4 T workgroups; workgroup b -> (XCD, tile, quarter), see
-// ggd_block_to_tile).
+// ggd_block_to_tile).  A PERSISTENT form -- as many workgroups as the device holds, each drawing (tile, quarter) tickets
+// from atomic counters, next ticket requested before the current tile is started -- was built and measured in round 4
+// (commit 1e08ef1, profiles/r04/persist_ab_*.txt): 413 us with one counter per XCD, 184 us with 64 counters per XCD, against
+// 104 us for this one-shot launch at 1 M / 1024^2 (shell 260 vs 194, 100 k / 512^2 79 vs 25): the same waves take the same
+// time per tile, but 3.8 instead of 5.4 of them are at work per SIMD -- a ticket is a returning atomic's round trip through
+// memory, the hardware dispatcher back-fills a finished wave's slot without one.  Removed again.
 template <int EXP_MODE, bool CULL, int PXL, int BW, bool STATS>
 __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx, int T,
                                                            const ggd_splat* __restrict__ splat,
@@ -451,54 +456,6 @@ __global__ __launch_bounds__(64) void blend_forward_kernel(int W, int H, int gx,
   __shared__ float4 s_rec[64 * 3];
   blend_forward_block<EXP_MODE, CULL, PXL, BW, STATS>((int)blockIdx.x, s_rec, W, H, gx, T, splat, list, ranges, capacity, bg,
                                                       out_color, final_T, n_contrib, stats);
-}
-
-// PERSISTENT form (GGD_OPT_BLEND_PERSIST = 1; an experiment): as many single-wave workgroups as the device
-// holds at once, each drawing (tile, quarter) tickets until none is left.  Workgroup w lives on XCD w % 8; ticket q of XCD x
-// is the one-shot launch's workgroup 8 q + x, so the four quarters of a tile still share one XCD's L2.  ONE counter per XCD
-// (2048 draws each at 1 M / 1024^2) made the kernel 4 x slower: returning atomics on one address complete at ~0.2 us apiece,
-// whoever issues them.  Hence GGD_TICKET_SLICES counters per XCD: slice g owns the tile slots t = g (mod SLICES) of its XCD
-// and is drawn from by the workgroups w with (w / 8) % SLICES == g; draw k of a slice is quarter k % 4 of its tile slot
-// k / 4, so the four quarters of a tile go to four workgroups at about the same time.  A workgroup asks for its next ticket
-// before it starts on the current one (the atomic's round trip runs under the blend).  The last workgroup to run dry zeroes
-// the counters for the next launch.
-constexpr int GGD_TICKET_SLICES = 64;
-template <int EXP_MODE, bool CULL, bool STATS>
-__global__ __launch_bounds__(64) void blend_forward_persistent_kernel(int W, int H, int gx, int T,
-                                                                      const ggd_splat* __restrict__ splat,
-                                                                      const uint32_t* __restrict__ list,
-                                                                      const uint32_t* __restrict__ ranges, uint32_t capacity,
-                                                                      const float* __restrict__ bg,
-                                                                      float* __restrict__ out_color,
-                                                                      float* __restrict__ final_T,
-                                                                      uint32_t* __restrict__ n_contrib,
-                                                                      unsigned long long* __restrict__ stats,
-                                                                      uint32_t* __restrict__ tickets /*[8][SLICES] + done*/) {
-  __shared__ float4 s_rec[64 * 3];
-  // slices in use: every slice needs at least one workgroup per XCD to draw from it (small grids launch few workgroups)
-  const uint32_t nsl = min((uint32_t)GGD_TICKET_SLICES, gridDim.x >> 3);
-  const uint32_t xcd = blockIdx.x & 7u, slice = (blockIdx.x >> 3) % nsl;
-  uint32_t* counter = tickets + xcd * GGD_TICKET_SLICES + slice;
-  const uint32_t total = 4u * (uint32_t)T;
-  uint32_t k_next = 0;
-  if (threadIdx.x == 0) k_next = atomicAdd(counter, 1u);
-  for (;;) {
-    const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_next);
-    const uint32_t q = 4u * (slice + nsl * (k >> 2)) + (k & 3u);   // tile slot, quarter -> position in the XCD's stream
-    const uint32_t b = 8u * q + xcd;
-    if (b >= total) break;
-    if (threadIdx.x == 0) k_next = atomicAdd(counter, 1u);     // consumed after this ticket's tile
-    blend_forward_block<EXP_MODE, CULL, 1, 8, STATS>((int)b, s_rec, W, H, gx, T, splat, list, ranges, capacity, bg, out_color,
-                                                     final_T, n_contrib, stats);
-    __syncthreads();   // single-wave block: the tile's last LDS reads before the next tile's first writes
-  }
-  if (threadIdx.x == 0) {
-    uint32_t* done_ctr = tickets + 8 * GGD_TICKET_SLICES;
-    const uint32_t done = atomicAdd(done_ctr, 1u);
-    if (done == gridDim.x - 1u) {          // everybody has drawn a ticket past the end: nobody touches the counters again
-      for (int i = 0; i <= 8 * GGD_TICKET_SLICES; ++i) __hip_atomic_store(&tickets[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
 }
 
 // Backward blend: the per-record update of ONE pixel, shared by the two kernel forms below.  Records are visited back to
@@ -973,30 +930,9 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
   const int em = ctx->opt[GGD_OPT_EXP_MODE];
   const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
   const int T = gx * gy;
-  const bool persist = ctx->opt[GGD_OPT_BLEND_PERSIST] != 0;
-  uint32_t* tickets = ctx->blend_tickets;  // [8][GGD_TICKET_SLICES] ticket counters | done: zero between launches (the kernel resets them)
-  if (persist && !tickets) {
-    GGD_HIP(hipMalloc((void**)&ctx->blend_tickets, (8 * GGD_TICKET_SLICES + 1) * sizeof(uint32_t)));
-    GGD_HIP(hipMemsetAsync(ctx->blend_tickets, 0, (8 * GGD_TICKET_SLICES + 1) * sizeof(uint32_t), s));
-    tickets = ctx->blend_tickets;
-  }
-  if (persist && ctx->persist_grid == 0) {
-    int per_cu = 0, cus = 0;
-    GGD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &per_cu, reinterpret_cast<const void*>(blend_forward_persistent_kernel<2, true, false>), 64, 0));
-    GGD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-    ctx->persist_grid = max(8, (per_cu * cus) & ~7);
-  }
 #define GGD_LAUNCH_FWD2(EM, CU, ST)                                                                                     \
-  do {                                                                                                                  \
-    if (persist)                                                                                                        \
-      hipLaunchKernelGGL((blend_forward_persistent_kernel<EM, CU, ST>), dim3(min(ctx->persist_grid, (4 * T + 7) & ~7)), \
-                         dim3(64), 0, s, prm.width, prm.height, gx, T, splat, list, ranges, capacity, prm.bg, out_color, \
-                         final_T, n_contrib, ctx->blend_stats, tickets);                                                \
-    else                                                                                                                \
-      hipLaunchKernelGGL((blend_forward_kernel<EM, CU, 1, 8, ST>), dim3(4 * T), dim3(64), 0, s, prm.width, prm.height,  \
-                         gx, T, splat, list, ranges, capacity, prm.bg, out_color, final_T, n_contrib, ctx->blend_stats); \
-  } while (0)
+  hipLaunchKernelGGL((blend_forward_kernel<EM, CU, 1, 8, ST>), dim3(4 * T), dim3(64), 0, s, prm.width, prm.height,      \
+                     gx, T, splat, list, ranges, capacity, prm.bg, out_color, final_T, n_contrib, ctx->blend_stats)
 #define GGD_LAUNCH_FWD(EM, CU)                                                                                          \
   do {                                                                                                                  \
     if (ctx->blend_stats) GGD_LAUNCH_FWD2(EM, CU, true); else GGD_LAUNCH_FWD2(EM, CU, false);                           \

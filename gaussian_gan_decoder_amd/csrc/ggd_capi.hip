@@ -112,7 +112,6 @@ extern "C" ggd_ctx* ggd_create(int device) {
   if (const char* e = getenv("GGD_BINNING")) { const int v = atoi(e); if (v >= 0 && v <= 3) ctx->opt[GGD_OPT_BINNING] = v; }
   if (const char* e = getenv("GGD_BLEND_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 4) ctx->opt[GGD_OPT_BLEND_SPLIT] = v; }
   if (const char* e = getenv("GGD_BLEND_CULL")) ctx->opt[GGD_OPT_BLEND_CULL] = atoi(e) != 0;
-  if (const char* e = getenv("GGD_BLEND_PERSIST")) ctx->opt[GGD_OPT_BLEND_PERSIST] = atoi(e) != 0;
   int prev = 0;
   (void)hipGetDevice(&prev);
   bool ok = hipSetDevice(device) == hipSuccess &&
@@ -151,7 +150,6 @@ extern "C" void ggd_destroy(ggd_ctx* ctx) {
   if (ctx->d_words) (void)hipFree(ctx->d_words);
   if (ctx->h_words) (void)hipHostFree(ctx->h_words);
   if (ctx->sortctl) (void)hipFree(ctx->sortctl);
-  if (ctx->blend_tickets) (void)hipFree(ctx->blend_tickets);
   if (ctx->scan_sums) (void)hipFree(ctx->scan_sums);
   if (ctx->stats_buf) (void)hipFree(ctx->stats_buf);
   if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);
@@ -165,7 +163,7 @@ extern "C" const char* ggd_last_error(ggd_ctx* ctx) { return ctx ? ctx->err.c_st
 
 extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
   if (!ctx) return GGD_E_INVALID;
-  static const int kMax[GGD_OPT_COUNT] = {2, 1, 3, 4, 1};
+  static const int kMax[GGD_OPT_COUNT] = {2, 1, 3, 4};
   if (option < 0 || option >= GGD_OPT_COUNT || value < 0 || value > kMax[option])
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_set_option: unknown option or value");
   ctx->opt[option] = value;

@@ -40,14 +40,12 @@ struct ggd_ctx {
   uint32_t* scan_sums = nullptr;    // block sums of a scan that rides on the depth sort (own allocation, grow-only)
   int scan_sums_cap = 0;
   bool scan_deferred = false;       // geometry_enqueue left the scan to the sort launches of the same call
-  uint32_t* blend_tickets = nullptr; // ticket counters of the persistent forward blend (allocated on first use)
-  int persist_grid = 0;             // workgroups of the persistent forward blend (occupancy x CUs), 0 = not queried yet
   uint32_t r_tag = 0;               // sequence number of the single-call forward whose num_rendered the host is waiting for
   bool r_pending = false;           // the host waits for the tagged word (h_words[2..3]), not for the end of the frame
   void* dbg_keys = nullptr;     // debug copy of the unsorted list
   void* dbg_vals = nullptr;
   size_t dbg_cap = 0;
-  int opt[GGD_OPT_COUNT] = {2, 1, 1, 1, 0};  // exp: compensated 2^x (1-ulp class like ocml expf, ~8 % faster blend)
+  int opt[GGD_OPT_COUNT] = {2, 1, 1, 1};  // exp: compensated 2^x (1-ulp class like ocml expf, ~8 % faster blend)
   unsigned long long* blend_stats = nullptr;  // debug: device counters filled by the forward blend when non-null
   unsigned long long* stats_buf = nullptr;    // its storage: [0..4] counters, [GGD_STATS_MODE] 1 = per-wave timeline, slots from GGD_STATS_HEAD
   bool profiling = false;

@@ -210,8 +210,6 @@ enum {
                              4 = four independent quarter waves per tile; 1 (default) = auto (4 from 2048 tiles, else 3);
                              0, 2 = aliases of 3 (the one-wave and two-wave forms they selected were removed).  Backward sums
                              differ only in their fp32 summation order. */
-  GGD_OPT_BLEND_PERSIST = 4, /* forward blend: 0 (default) = one workgroup per (tile, quarter); 1 = as many workgroups as
-                             the device holds, each drawing (tile, quarter) tickets.  Images are identical. */
   GGD_OPT_COUNT
 };
 int ggd_set_option(ggd_ctx* ctx, int option, int value);

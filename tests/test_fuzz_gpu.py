@@ -26,7 +26,7 @@ def _case(seed):
     d = scene_inputs(P=P, size=max(W, H), kind=str(rng.choice(["cube", "shell"])), seed=seed, sh_degree=0 if use_colors else deg,
                      sh_M=None if use_colors else M, use_colors=use_colors, use_cov=use_cov, lsm=float(rng.uniform(-6.5, -3.0)),
                      fov_deg=float(rng.uniform(6.0, 20.0)), width=W, height=H, scale_modifier=float(rng.choice([1.0, 0.7, 1.6])))
-    opts = dict(binning=int(rng.choice([0, 1, 2, 3])), split=int(rng.choice([1, 3, 4])), persist=int(rng.rand() < 0.3), cull=int(rng.rand() < 0.8),
+    opts = dict(binning=int(rng.choice([0, 1, 2, 3])), split=int(rng.choice([1, 3, 4])), cull=int(rng.rand() < 0.8),
                 exp_mode=int(rng.choice([0, 2])))
     return d, opts
 
@@ -39,10 +39,10 @@ def test_random_configuration_matches_oracle(native_lib, seed):
     o = run_oracle(d)
     frag = fragile_pixels(o)
     cx = _capi.context_for(torch.device("cuda:0"))
-    saved = [cx.get_option(k) for k in (_capi.OPT_BLEND_SPLIT, _capi.OPT_BLEND_CULL, _capi.OPT_EXP_MODE, _capi.OPT_BLEND_PERSIST)]
+    saved = [cx.get_option(k) for k in (_capi.OPT_BLEND_SPLIT, _capi.OPT_BLEND_CULL, _capi.OPT_EXP_MODE)]
     try:
         cx.set_option(_capi.OPT_BLEND_SPLIT, opts["split"]); cx.set_option(_capi.OPT_BLEND_CULL, opts["cull"])
-        cx.set_option(_capi.OPT_EXP_MODE, opts["exp_mode"]); cx.set_option(_capi.OPT_BLEND_PERSIST, opts["persist"])
+        cx.set_option(_capi.OPT_EXP_MODE, opts["exp_mode"])
         for rep in range(2):      # the second call of a shape takes the single-call (capacity hint) form where it exists
             n = run_native(d, debug=False, binning=opts["binning"])
             assert n["num_rendered"] == o["num_rendered"], (opts, W, H, P)
@@ -59,6 +59,6 @@ def test_random_configuration_matches_oracle(native_lib, seed):
         nb = run_native_backward(d, n, g)
         assert check_gradients(d, nb, ref, budget, fragile) <= 1.0, opts
     finally:
-        for k, v in zip((_capi.OPT_BLEND_SPLIT, _capi.OPT_BLEND_CULL, _capi.OPT_EXP_MODE, _capi.OPT_BLEND_PERSIST), saved):
+        for k, v in zip((_capi.OPT_BLEND_SPLIT, _capi.OPT_BLEND_CULL, _capi.OPT_EXP_MODE), saved):
             cx.set_option(k, v)
         cx.set_option(_capi.OPT_BINNING, 1)

@@ -268,28 +268,25 @@ def test_wide_grid_row_binning_survives_capacity_overflow(native_lib, W, H):
 
 
 def test_blend_options_do_not_change_the_image(native_lib):
-    """Wave-level culling (GGD_OPT_BLEND_CULL) and the ticket-drawing persistent form of the forward
-    (GGD_OPT_BLEND_PERSIST) are exact optimisations: image, final_T and n_contrib are bit-identical with them on or off,
-    also on a grid whose tile count is not a multiple of 8 and several frames in a row (the persistent kernel leaves its
-    ticket counters clean for the next launch).  The exp variants (GGD_OPT_EXP_MODE 0/1/2) may differ by ulps only:
-    <= 1e-5 against each other."""
+    """Wave-level culling (GGD_OPT_BLEND_CULL) is an exact optimisation: image, final_T and n_contrib are bit-identical
+    with it on or off, also on a grid whose tile count is not a multiple of 8 (the other workgroup -> tile mapping).  The
+    exp variants (GGD_OPT_EXP_MODE 0/1/2) may differ by ulps only: <= 1e-5 against each other."""
     from gaussian_gan_decoder_amd import _capi
     cx = _capi.context_for(torch.device("cuda:0"))
-    saved = [cx.get_option(o) for o in (_capi.OPT_EXP_MODE, _capi.OPT_BLEND_CULL, _capi.OPT_BLEND_PERSIST)]
+    saved = [cx.get_option(o) for o in (_capi.OPT_EXP_MODE, _capi.OPT_BLEND_CULL)]
     try:
         for size, W, H in ((256, None, None), (208, 208, 176)):      # 256 tiles | 13 x 11 = 143 tiles
             d = scene_inputs(P=20000, size=size, kind="shell", lsm=-4.5, **({} if W is None else dict(width=W, height=H)))
-            cx.set_option(_capi.OPT_BLEND_CULL, saved[1]); cx.set_option(_capi.OPT_BLEND_PERSIST, 0)
+            cx.set_option(_capi.OPT_BLEND_CULL, saved[1])
             base = run_native(d, debug=False)
             for cull in (0, 1):
-                for persist in (0, 1, 1):
-                    cx.set_option(_capi.OPT_BLEND_CULL, cull); cx.set_option(_capi.OPT_BLEND_PERSIST, persist)
-                    n = run_native(d, debug=False)
-                    np.testing.assert_array_equal(n["color"].cpu().numpy(), base["color"].cpu().numpy())
-                    np.testing.assert_array_equal(n["n_contrib"], base["n_contrib"])
-                    np.testing.assert_array_equal(n["final_T"], base["final_T"])
+                cx.set_option(_capi.OPT_BLEND_CULL, cull)
+                n = run_native(d, debug=False)
+                np.testing.assert_array_equal(n["color"].cpu().numpy(), base["color"].cpu().numpy())
+                np.testing.assert_array_equal(n["n_contrib"], base["n_contrib"])
+                np.testing.assert_array_equal(n["final_T"], base["final_T"])
         d = scene_inputs(P=20000, size=256, kind="shell", lsm=-4.5)
-        cx.set_option(_capi.OPT_BLEND_CULL, saved[1]); cx.set_option(_capi.OPT_BLEND_PERSIST, saved[2])
+        cx.set_option(_capi.OPT_BLEND_CULL, saved[1])
         base = run_native(d, debug=False)
         for em in (0, 1, 2):
             cx.set_option(_capi.OPT_EXP_MODE, em)
@@ -299,7 +296,7 @@ def test_blend_options_do_not_change_the_image(native_lib):
             err = np.abs(n["color"].cpu().numpy() - base["color"].cpu().numpy())[:, same]
             assert err.max() <= RGB_ATOL
     finally:
-        for o, v in zip((_capi.OPT_EXP_MODE, _capi.OPT_BLEND_CULL, _capi.OPT_BLEND_PERSIST), saved):
+        for o, v in zip((_capi.OPT_EXP_MODE, _capi.OPT_BLEND_CULL), saved):
             cx.set_option(o, v)
 
 
