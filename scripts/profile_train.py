@@ -4,8 +4,13 @@ import torch
 from gaussian_gan_decoder_amd.train import DecoderTrainer, make_scene_batch
 dev = torch.device('cuda:0')
 fused = '--fused' in sys.argv
+# --standins: bench.py's configuration (backbone gradient payload + the perceptual slot); --eg3d: tri-planes instead of the
+# PanoHead tri-grids BASELINE config 3 names
+planes = dict() if '--eg3d' in sys.argv else dict(plane_axes="panohead", triplane_depth=3)
+standins = dict(backbone_params=29_570_000 - 3 * 32 * (1 if '--eg3d' in sys.argv else 3) * 256 * 256, perceptual_weight=1.0) \
+    if '--standins' in sys.argv else dict()
 tr = DecoderTrainer(dev, n_scenes_total=4, image_size=512, fused_activations=True, fused_decoder=fused,
-                    decoder_precision='fp32' if '--fp32' in sys.argv else 'bf16')
+                    decoder_precision='fp32' if '--fp32' in sys.argv else 'bf16', **planes, **standins)
 b = make_scene_batch([0,1,2,3], 500000, 512, dev, seed=0)
 for _ in range(2): tr.step(b)
 torch.cuda.synchronize()
