@@ -465,7 +465,7 @@ extern "C" int ggd_decoder_backward_wgrad(ggd_ctx* ctx, void* stream, int32_t N,
 
 // ---- the decoder at reference precision (split bf16 operands, csrc/ggd_mlp_hl.inc) -------------------------------------------
 extern "C" size_t ggd_decoder_packed_hl_bytes(void) { return (size_t)NHEAD * HLF_HEAD; }
-extern "C" size_t ggd_decoder_dzbuf_hl_bytes(int32_t N) { return 2 * ggd_decoder_zbuf_bytes(N); }   // dz: hi plane | lo plane (z: one fp16 plane, ggd_decoder_zbuf_bytes)
+extern "C" size_t ggd_decoder_dzbuf_hl_bytes(int32_t N) { return ggd_decoder_zbuf_bytes(N); }   // dz: one loss-scaled fp16 plane (z: one fp16 plane, ggd_decoder_zbuf_bytes)
 extern "C" size_t ggd_decoder_packed_t_hl_bytes(void) { return (size_t)NHEAD * HLT_HEAD; }
 
 extern "C" int ggd_decoder_pack_hl(ggd_ctx* ctx, void* stream, const float* const* params40, void* packed_hl,
@@ -493,7 +493,7 @@ static int hl_attributes(ggd_ctx* ctx) {
   GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_backward_hl_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)HL_LDS_BWD));
   GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_wgrad_hl_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WGH_LDS));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
   ctx->attr_mask |= GGD_ATTR_MLP_HL;
   return GGD_OK;
 }
@@ -532,6 +532,15 @@ extern "C" int ggd_decoder_backward_wgrad_hl(ggd_ctx* ctx, void* stream, int32_t
   const int rc = hl_attributes(ctx);
   if (rc != GGD_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // scales of the fp16 dz planes: one exponent per (head, 32-point slab) written by the backward, the largest per head
+  // (library scratch: both kernels of this call, nothing in between)
+  const int64_t nslab = ((int64_t)N + SLAB - 1) / SLAB;
+  const size_t kbytes = ggd_align((size_t)NHEAD * nslab * sizeof(int)) + 256;
+  int rck = ggd_reserve_scratch(ctx, kbytes, s);
+  if (rck != GGD_OK) return rck;
+  int* karr = static_cast<int*>(ctx->scratch);
+  int* kref = reinterpret_cast<int*>(static_cast<char*>(ctx->scratch) + ggd_align((size_t)NHEAD * nslab * sizeof(int)));
+  GGD_HIP(hipMemsetAsync(kref, 0x80, 64, s));     // every byte 0x80: far below any exponent (atomicMax target); < HL_KNONE is never stored
   if (chunk <= 0 || chunk > N) chunk = N;
   chunk = (chunk + 255) / 256 * 256;
   for (int32_t first = 0; first < N; first += chunk) {
@@ -541,12 +550,12 @@ extern "C" int ggd_decoder_backward_wgrad_hl(ggd_ctx* ctx, void* stream, int32_t
     if (grid > 256) grid = 256;
     hipLaunchKernelGGL(decoder_backward_hl_kernel, dim3(grid), dim3(MLP_THREADS), HL_LDS_BWD, s, N, first, last,
                        static_cast<const unsigned char*>(packed_t_hl), attrs, dattrs, static_cast<const __bf16*>(zbuf),
-                       static_cast<__bf16*>(dzbuf), dout, dfeat, dinfo);
+                       static_cast<__bf16*>(dzbuf), dout, dfeat, dinfo, karr, kref);
     int chunks = (n + 4 * WG_K - 1) / (4 * WG_K);
     if (chunks > 128) chunks = 128;
     if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL(decoder_wgrad_hl_kernel, dim3(chunks, NHEAD * 4), dim3(WG_THREADS), WGH_LDS, s, N, first, last,
-                       static_cast<const __bf16*>(zbuf), static_cast<const __bf16*>(dzbuf), dout, feat, pos, attrs, wgrad);
+    hipLaunchKernelGGL(decoder_wgrad_hl_kernel, dim3(chunks, NHEAD * 4), dim3(WG_THREADS), WG_LDS, s, N, first, last,
+                       static_cast<const __bf16*>(zbuf), static_cast<const __bf16*>(dzbuf), dout, feat, pos, attrs, wgrad, karr, kref);
   }
   GGD_HIP(hipGetLastError());
   return GGD_OK;

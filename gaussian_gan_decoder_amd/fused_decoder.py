@@ -219,8 +219,9 @@ class FusedDecoderFn(torch.autograd.Function):
         n = pos.shape[0]
         dattrs = dattrs.contiguous().float()
         cx = _capi.context_for(dev)
-        # dz: one bf16 plane, or two (hi | lo) at reference precision
-        dzbuf = torch.empty(((2 if ctx.hl else 1),) + tuple(zbuf.shape), dtype=torch.bfloat16, device=dev)
+        # dz: one 16-bit plane in z's blocked layout (bf16 kernels: bf16 values; reference precision: loss-scaled fp16 values,
+        # the scale chosen on the device from max |dattrs| -- csrc/ggd_mlp_hl.inc)
+        dzbuf = torch.empty(tuple(zbuf.shape), dtype=torch.bfloat16, device=dev)
         dout = torch.empty((5, n, 4), dtype=torch.float32, device=dev)
         dfeat = torch.empty((n, 32), dtype=torch.float32, device=dev)
         dinfo = torch.empty((n, 16), dtype=torch.float32, device=dev)

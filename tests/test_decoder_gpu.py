@@ -350,3 +350,70 @@ def test_fused_decoder_fp32_precision_training_gradients(native_lib):
     print("\n  relative L2 error of the gradients: max %.2e (%s), planes %.2e" % (max(r for _, r in report), max(report, key=lambda t: t[1])[0], report[0][1]))
     for name, r in report:
         assert r <= 1e-3, (name, r)
+
+
+@pytest.mark.parametrize("loss_scale", [1e-9, 1.0, 3e4])
+def test_fused_decoder_fp32_precision_gradients_do_not_depend_on_the_loss_scale(native_lib, loss_scale):
+    """The reference-precision kernels keep dz as ONE fp16 plane, every (head, 32-point slab) scaled by its own power of two
+    taken from the slab's largest gradient at that head's output (csrc/ggd_mlp_hl.inc): gradients of a loss as small as a mean-reduced image loss (1e-9 per point) or as large as
+    3e4 per point must come out with the same RELATIVE accuracy (<= 1e-3 relative L2 against float64 autograd) -- no
+    underflow to zero, no overflow to inf.  The per-point weights span four decades (occluded points get tiny gradients next
+    to the visible ones', as in a rendered scene)."""
+    from gaussian_gan_decoder_amd.fused_decoder import FusedTrainDecoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    ref = SequentialDecoderReverse().to(dev)
+    fused_mod = SequentialDecoderReverse().to(dev)
+    fused_mod.load_state_dict(ref.state_dict())
+    ref = ref.double()
+    fused = FusedTrainDecoder(fused_mod, precision="fp32")
+    N = 60_000
+    planes_a = torch.randn(3, 32, 64, 64, device=dev, dtype=torch.float64, requires_grad=True)
+    planes_b = planes_a.detach().float().requires_grad_(True)
+    pos = torch.rand(N, 3, device=dev) - 0.5
+    g = torch.Generator().manual_seed(6)
+    decade = 10.0 ** (-4.0 * torch.rand(N, 1, generator=g))
+    w = {k: (torch.randn(N, d, generator=g) * decade * loss_scale).to(dev)
+         for k, d in (("color", 3), ("opacity", 1), ("rotation", 4), ("scale", 3), ("xyz", 3))}
+
+    def loss(o):
+        return sum((getattr(o, k) * w[k].to(getattr(o, k).dtype)).sum() for k in w)
+    loss(ref(planes_a, pos.double())).backward()
+    loss(fused(planes_b, pos)).backward()
+    worst = ("planes", ((planes_a.grad - planes_b.grad.double()).norm() / planes_a.grad.norm()).item())
+    for (na, pa), (nb, pb) in zip(ref.named_parameters(), fused_mod.named_parameters()):
+        assert torch.isfinite(pb.grad).all(), nb
+        r = ((pa.grad - pb.grad.double()).norm() / (pa.grad.norm() + 1e-300)).item()
+        worst = max(worst, (na, r), key=lambda t: t[1])
+    print(f"\n  loss scale {loss_scale:g}: worst relative L2 gradient error {worst[1]:.2e} ({worst[0]})")
+    assert worst[1] <= 1e-3, worst
+
+
+def test_fused_decoder_fp32_precision_survives_pre_activations_beyond_fp16(native_lib):
+    """z is kept as one fp16 plane: a pre-activation beyond +-65504 is clamped there when it is stored (gelu' is 0 / 1 on
+    both sides of the clamp), so the gradients stay finite and the affected rows' inputs still get gradients of the
+    right size.  (Stored unclamped it became inf, gelu(inf) * 0 = NaN, and the trainer's nan_to_num silently zeroed whole
+    weight-gradient elements.)"""
+    from gaussian_gan_decoder_amd.fused_decoder import FusedTrainDecoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    mod = SequentialDecoderReverse().to(dev)
+    with torch.no_grad():
+        mod.color_decoder.backbone[0].weight *= 4.0e4     # first-layer pre-activations of the colour head ~ 1e5
+    ref = SequentialDecoderReverse().to(dev)
+    ref.load_state_dict(mod.state_dict())
+    ref = ref.double()
+    fused = FusedTrainDecoder(mod, precision="fp32")
+    N = 20_000
+    planes_a = torch.randn(3, 32, 32, 32, device=dev, dtype=torch.float64, requires_grad=True)
+    planes_b = planes_a.detach().float().requires_grad_(True)
+    pos = torch.rand(N, 3, device=dev) - 0.5
+    oa, ob = ref(planes_a, pos.double()), fused(planes_b, pos)
+    (oa.color.sum() + oa.xyz.sum()).backward()
+    (ob.color.sum() + ob.xyz.sum()).backward()
+    for (na, pa), (nb, pb) in zip(ref.named_parameters(), mod.named_parameters()):
+        assert torch.isfinite(pb.grad).all(), nb
+        if pa.grad.norm() > 0:
+            r = ((pa.grad - pb.grad.double()).norm() / pa.grad.norm()).item()
+            assert r <= 5e-3, (na, r)
+    assert torch.isfinite(planes_b.grad).all()
