@@ -207,7 +207,10 @@ class FusedDecoderFn(torch.autograd.Function):
             cx.check(fwd(cx.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), C.c_void_p(feats.data_ptr()),
                          C.c_void_p(pos.data_ptr()), n, C.c_void_p(packed.data_ptr()), C.c_void_p(attrs.data_ptr()),
                          C.c_void_p(zbuf.data_ptr())))
-        ctx.save_for_backward(feats, pos, attrs, zbuf, packed_t)
+        # packed_t is rebuilt IN PLACE by the next forward (FusedTrainDecoder._images), through raw pointers autograd cannot
+        # version: the backward of a graph kept across an optimizer step would silently read the new weights.  The node keeps
+        # its own copy (0.9 MB, or 1.8 MB in the split form: one small device copy per forward).
+        ctx.save_for_backward(feats, pos, attrs, zbuf, packed_t.clone())
         ctx.param_shapes = [tuple(p.shape) for p in params]
         ctx.hl = bool(hl)
         return attrs
