@@ -35,3 +35,14 @@ for _ in range(10):
         if not k.endswith("_bwd"): acc[k] = acc.get(k, 0.0) + v / 10
 ctx.set_profiling(False)
 print(json.dumps({k: round(v * 1e3, 1) for k, v in acc.items()}), "visible", int((out["radii"] > 0).sum()))
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(50): out = frame()
+torch.cuda.synchronize()
+print("decode + render ms/frame", (time.perf_counter() - t) / 50 * 1e3)
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    for _ in range(3): out = frame()
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=50))
+print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=12, max_name_column_width=50))

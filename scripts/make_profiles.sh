@@ -18,9 +18,9 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/bench -o p --output-forma
     python $R/bench.py --steps 100 --backward --no-train --no-decode --no-sweep --no-cpu-baseline \
     > $R/gpurun_out/$TAG/bench_under_rocprof.json 2> $R/gpurun_out/$TAG/bench.err
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/train -o p --output-format csv -- \
-    python $R/scripts/profile_train.py --fused > $R/gpurun_out/$TAG/train.log 2>&1
+    python $R/scripts/profile_train.py --fused --standins > $R/gpurun_out/$TAG/train.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/train_fp32 -o p --output-format csv -- \
-    python $R/scripts/profile_train.py --fused --fp32 > $R/gpurun_out/$TAG/train_fp32.log 2>&1
+    python $R/scripts/profile_train.py --fused --fp32 --standins > $R/gpurun_out/$TAG/train_fp32.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/hd -o p --output-format csv -- \
     python $R/scripts/hd_timing.py > $R/gpurun_out/$TAG/hd_timing.txt 2>&1
 cd $R
