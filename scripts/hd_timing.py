@@ -10,7 +10,7 @@ for (P, W, H) in [(1_000_000, 1920, 1080), (1_000_000, 2048, 2048), (2_000_000, 
     args = (sc.bg, sc.xyz, e, sc.opacities.contiguous(), sc.scales.contiguous(), sc.rotations.contiguous(), 1.0, e, cam.world_view_transform,
             cam.full_proj_transform, math.tan(cam.FoVx*0.5), math.tan(cam.FoVx*0.5) * H / W, H, W, sc.features_dc.contiguous(), 0, cam.camera_center, False, False)
     ctx = _capi.context_for(dev)
-    for mode, name in ((1, "auto"), (0, "sort"), (2, "tilebin"), (3, "rowbin")):
+    for mode, name in ((1, "auto"), (0, "sort"), (3, "rowbin")):
         ctx.set_option(_capi.OPT_BINNING, mode)
         try:
             for _ in range(3): out = R.rasterize_gaussians_native(*args)
