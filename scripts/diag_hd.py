@@ -1,4 +1,4 @@
-"""Diagnostic: the 1920x1080 / 2048^2 large-splat cases against the oracle for every blend option (cull on/off, split forms)."""
+"""Diagnostic: the 1920x1080 / 2048^2 large-splat cases against the oracle for every blend option (cull on/off, backward forms)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,7 +13,7 @@ o = run_oracle(d)
 g = make_dL_dpix(max(W, H))[:, :H, :W].contiguous()
 cx = _capi.context_for(torch.device("cuda:0"))
 for cull in (1, 0):
-    for split in (1, 0, 2):
+    for split in (1, 3, 4):      # backward blend: auto, tile form, quarter form
         cx.set_option(_capi.OPT_BLEND_CULL, cull); cx.set_option(_capi.OPT_BLEND_SPLIT, split)
         n = run_native(d, debug=False)
         color = n["color"].cpu().numpy()
