@@ -18,7 +18,7 @@ EXPORTS = [
     "ggd_geom_bytes", "ggd_binning_bytes", "ggd_img_bytes", "ggd_geom_layout", "ggd_binning_layout",
     "ggd_img_layout", "ggd_sort_bits", "ggd_create", "ggd_destroy", "ggd_last_error", "ggd_version",
     "ggd_forward_geometry", "ggd_forward_render", "ggd_forward", "ggd_forward_can_speculate", "ggd_backward", "ggd_mark_visible", "ggd_debug_unsorted",
-    "ggd_triplane_forward", "ggd_triplane_backward", "ggd_trigrid_forward", "ggd_trigrid_backward", "ggd_planes_gather", "ggd_planes_scatter", "ggd_surface_tmp_bytes", "ggd_surface_sample", "ggd_decoder_packed_bytes", "ggd_decoder_pack", "ggd_decoder_forward", "ggd_decoder_zbuf_bytes", "ggd_decoder_packed_t_bytes",
+    "ggd_triplane_forward", "ggd_triplane_backward", "ggd_trigrid_forward", "ggd_trigrid_backward", "ggd_planes_gather", "ggd_planes_scatter", "ggd_surface_tmp_bytes", "ggd_surface_sample", "ggd_attrs_split", "ggd_attrs_merge", "ggd_decoder_packed_bytes", "ggd_decoder_pack", "ggd_decoder_forward", "ggd_decoder_zbuf_bytes", "ggd_decoder_packed_t_bytes",
     "ggd_decoder_forward_train", "ggd_decoder_backward", "ggd_decoder_wgrad_floats", "ggd_decoder_wgrad", "ggd_decoder_backward_wgrad", "ggd_decoder_packed_hl_bytes", "ggd_decoder_packed_t_hl_bytes", "ggd_decoder_dzbuf_hl_bytes", "ggd_decoder_pack_hl", "ggd_decoder_forward_hl", "ggd_decoder_backward_wgrad_hl", "ggd_image_loss_tmp_bytes", "ggd_image_loss", "ggd_set_option", "ggd_get_option", "ggd_blend_stats", "ggd_blend_timeline", "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
 ]
 
@@ -90,6 +90,8 @@ def load():
         lib.ggd_planes_scatter.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, C.c_float, vp, vp, i32]
         lib.ggd_surface_tmp_bytes.restype = sz; lib.ggd_surface_tmp_bytes.argtypes = [i32]
         lib.ggd_surface_sample.argtypes = [vp, vp, vp, i32, C.c_float, i32, C.c_float, C.c_uint64, vp, vp, vp, sz]
+        lib.ggd_attrs_split.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp, vp]
+        lib.ggd_attrs_merge.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp]
         lib.ggd_decoder_packed_bytes.restype = sz
         lib.ggd_decoder_pack.argtypes = [vp, vp, C.POINTER(C.c_void_p), vp, vp]
         lib.ggd_decoder_forward.argtypes = [vp, vp, vp, vp, i32, vp, vp]

@@ -358,6 +358,57 @@ static int decoder_forward_impl(ggd_ctx* ctx, void* stream, const float* feat, c
   return GGD_OK;
 }
 
+// attrs rows [N][16] <-> the five contiguous per-Gaussian arrays the rasterizer's entry takes (xyz [N][3], scale [N][3],
+// rotation [N][4], opacity [N][1], colour [N][3]); one pass each way instead of five strided torch copies per scene.
+// MERGE: the gradient row gets zeros where an array is NULL (an attribute the loss did not reach) and in the two unused slots.
+template <bool MERGE>
+__global__ __launch_bounds__(256) void attrs_split_kernel(float* __restrict__ attrs, int64_t N, float* __restrict__ xyz,
+                                                          float* __restrict__ scale, float* __restrict__ rot,
+                                                          float* __restrict__ opac, float* __restrict__ color) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  f4* row = reinterpret_cast<f4*>(attrs + n * 16);
+  if (!MERGE) {
+    const f4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];   // colour 3 | opacity, rotation 4, scale 3 | xyz.x, xyz.yz | 0 0
+    color[3 * n] = r0[0]; color[3 * n + 1] = r0[1]; color[3 * n + 2] = r0[2];
+    opac[n] = r0[3];
+    *reinterpret_cast<f4*>(rot + 4 * n) = r1;
+    scale[3 * n] = r2[0]; scale[3 * n + 1] = r2[1]; scale[3 * n + 2] = r2[2];
+    xyz[3 * n] = r2[3]; xyz[3 * n + 1] = r3[0]; xyz[3 * n + 2] = r3[1];
+  } else {
+    f4 r0 = {0, 0, 0, 0}, r1 = r0, r2 = r0, r3 = r0;
+    if (color) { r0[0] = color[3 * n]; r0[1] = color[3 * n + 1]; r0[2] = color[3 * n + 2]; }
+    if (opac) r0[3] = opac[n];
+    if (rot) r1 = *reinterpret_cast<const f4*>(rot + 4 * n);
+    if (scale) { r2[0] = scale[3 * n]; r2[1] = scale[3 * n + 1]; r2[2] = scale[3 * n + 2]; }
+    if (xyz) { r2[3] = xyz[3 * n]; r3[0] = xyz[3 * n + 1]; r3[1] = xyz[3 * n + 2]; }
+    row[0] = r0; row[1] = r1; row[2] = r2; row[3] = r3;
+  }
+}
+
+extern "C" int ggd_attrs_split(ggd_ctx* ctx, void* stream, const float* attrs, int64_t N, float* xyz, float* scale,
+                               float* rotation, float* opacity, float* color) {
+  if (!ctx) return GGD_E_INVALID;
+  if (N <= 0) return GGD_OK;
+  if (!attrs || !xyz || !scale || !rotation || !opacity || !color) return ggd_fail(ctx, GGD_E_INVALID, "ggd_attrs_split: NULL pointer");
+  hipLaunchKernelGGL(attrs_split_kernel<false>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     const_cast<float*>(attrs), N, xyz, scale, rotation, opacity, color);
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
+extern "C" int ggd_attrs_merge(ggd_ctx* ctx, void* stream, int64_t N, const float* dxyz, const float* dscale,
+                               const float* drotation, const float* dopacity, const float* dcolor, float* dattrs) {
+  if (!ctx) return GGD_E_INVALID;
+  if (N <= 0) return GGD_OK;
+  if (!dattrs) return ggd_fail(ctx, GGD_E_INVALID, "ggd_attrs_merge: NULL pointer");
+  hipLaunchKernelGGL(attrs_split_kernel<true>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dattrs, N, const_cast<float*>(dxyz), const_cast<float*>(dscale), const_cast<float*>(drotation),
+                     const_cast<float*>(dopacity), const_cast<float*>(dcolor));
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
 extern "C" int ggd_decoder_forward(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
                                    const void* packed_weights, float* attrs) {
   return decoder_forward_impl(ctx, stream, feat, pos, N, packed_weights, attrs, nullptr);

@@ -255,29 +255,50 @@ class FusedDecoderFn(torch.autograd.Function):
 
 class _SplitAttrs(torch.autograd.Function):
     """attrs[B,N,16] -> per scene the five contiguous tensors the rasterizer takes (xyz, scale, rotation, opacity,
-    colour).  One autograd node: the backward writes the 5*B incoming gradients straight into one [B,N,16] buffer instead
-    of autograd's chain of select / slice backward nodes (each of which zero-fills a full-size tensor and adds it)."""
+    colour).  One autograd node and one HIP pass per scene each way (ggd_attrs_split / ggd_attrs_merge): autograd's own
+    chain of select / slice / contiguous nodes costs five strided copies per scene forward, and backward a zero-filled
+    full-size tensor plus an add per slice."""
     COLS = ((11, 14), (8, 11), (4, 8), (3, 4), (0, 3))   # xyz, scale, rotation, opacity, colour
 
     @staticmethod
     def forward(ctx, attrs):
         ctx.shape = attrs.shape
-        return tuple(attrs[b, :, lo:hi].contiguous() for b in range(attrs.shape[0]) for lo, hi in _SplitAttrs.COLS)
+        B, N, _ = attrs.shape
+        if not attrs.is_cuda:
+            return tuple(attrs[b, :, lo:hi].contiguous() for b in range(B) for lo, hi in _SplitAttrs.COLS)
+        attrs = attrs.contiguous().float()
+        dev = attrs.device
+        cx = _capi.context_for(dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        outs = []
+        with torch.cuda.device(dev):
+            for b in range(B):
+                o = [torch.empty((N, hi - lo), dtype=torch.float32, device=dev) for lo, hi in _SplitAttrs.COLS]
+                cx.check(cx.lib.ggd_attrs_split(cx.handle, stream, C.c_void_p(attrs[b].data_ptr()), N,
+                                                *[C.c_void_p(t.data_ptr()) for t in o]))
+                outs += o
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         B, N, _ = ctx.shape
         g0 = next(g for g in grads if g is not None)
-        d = torch.empty(ctx.shape, dtype=g0.dtype, device=g0.device)
-        d[:, :, 14:16] = 0
-        k = 0
-        for b in range(B):
-            for lo, hi in _SplitAttrs.COLS:
-                if grads[k] is None:
-                    d[b, :, lo:hi] = 0
-                else:
-                    d[b, :, lo:hi] = grads[k]
-                k += 1
+        if not g0.is_cuda:
+            d = torch.zeros(ctx.shape, dtype=g0.dtype, device=g0.device)
+            for k, g in enumerate(grads):
+                if g is not None:
+                    lo, hi = _SplitAttrs.COLS[k % 5]
+                    d[k // 5, :, lo:hi] = g
+            return d
+        dev = g0.device
+        d = torch.empty(ctx.shape, dtype=torch.float32, device=dev)
+        cx = _capi.context_for(dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            for b in range(B):
+                gs = [None if g is None else g.contiguous().float() for g in grads[5 * b:5 * b + 5]]
+                cx.check(cx.lib.ggd_attrs_merge(cx.handle, stream, N, *[None if g is None else C.c_void_p(g.data_ptr()) for g in gs],
+                                                C.c_void_p(d[b].data_ptr())))
         return d
 
 

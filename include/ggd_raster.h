@@ -293,6 +293,12 @@ size_t ggd_decoder_packed_bytes(void);
  * in = 35, 38, 39, 43, 46, out = 3, 1, 4, 3, 3); packed: ggd_decoder_packed_bytes(), packed_t (may be NULL):
  * ggd_decoder_packed_t_bytes().  Training calls it after every optimizer step. */
 int ggd_decoder_pack(ggd_ctx* ctx, void* stream, const float* const* params40, void* packed, void* packed_t);
+/* attrs rows [N][16] -> the five contiguous arrays the rasterizer entry takes (what the reference assigns to the GaussianModel,
+ * main/train_pano2gaussian_decoder.py:223-227), and the gradients back into rows (a NULL array = zeros): one pass each way. */
+int ggd_attrs_split(ggd_ctx* ctx, void* stream, const float* attrs, int64_t N, float* xyz, float* scale, float* rotation,
+                    float* opacity, float* color);
+int ggd_attrs_merge(ggd_ctx* ctx, void* stream, int64_t N, const float* dxyz, const float* dscale, const float* drotation,
+                    const float* dopacity, const float* dcolor, float* dattrs);
 int ggd_decoder_forward(ggd_ctx* ctx, void* stream, const float* feat, const float* pos, int32_t N,
                         const void* packed_weights, float* attrs);
 

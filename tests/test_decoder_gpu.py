@@ -417,3 +417,24 @@ def test_fused_decoder_fp32_precision_survives_pre_activations_beyond_fp16(nativ
             r = ((pa.grad - pb.grad.double()).norm() / pa.grad.norm()).item()
             assert r <= 5e-3, (na, r)
     assert torch.isfinite(planes_b.grad).all()
+
+
+def test_split_attrs_on_the_gpu_matches_slicing(native_lib):
+    """fused_decoder.split_attrs on CUDA tensors (one HIP pass per scene each way: ggd_attrs_split / ggd_attrs_merge) == the
+    slices it replaces, values and gradients, including an output that receives no gradient (zeros in its columns)."""
+    from gaussian_gan_decoder_amd import fused_decoder as FD
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    a = torch.randn(3, 1001, 16, device=dev, requires_grad=True)
+    parts = FD.split_attrs(a)
+    for b in range(3):
+        for t, (lo, hi) in zip(parts[b], FD._SplitAttrs.COLS):
+            assert t.is_contiguous() and torch.equal(t, a[b, :, lo:hi])
+    w = [[torch.randn_like(t) for t in scene] for scene in parts]
+    sum((t * wt).sum() for scene, ws in zip(parts, w) for t, wt in zip(scene, ws) if t.shape[1] != 4).backward()
+    ref = torch.zeros_like(a)
+    for b in range(3):
+        for (lo, hi), wt in zip(FD._SplitAttrs.COLS, w[b]):
+            if hi - lo != 4:
+                ref[b, :, lo:hi] = wt
+    assert torch.equal(a.grad, ref)
