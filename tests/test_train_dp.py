@@ -90,6 +90,64 @@ def test_gloo_data_parallel_step_matches_single_process(tmp_path, world):
     assert (ref - init).abs().max() > 1e-5
 
 
+def _guard_worker(rank, world, port, out_dir):
+    """(a) a second backward before allreduce_and_step() must raise (its gradients would be added to slices whose all-reduce
+    is already in flight and never be reduced); (b) after that failed step, step() re-arms the units and the ranks still
+    agree; (c) two backward passes under no_sync() + one outside == one backward of the summed loss."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import gaussian_gan_decoder_amd.train as T
+    T.BUCKET_BYTES = 8192
+    tr = _make_trainer(world)
+    batch = make_scene_batch([rank], N_POINTS, CFG["image_size"], "cpu", seed=0)
+    # (a)
+    tr.flat_grad.zero_()
+    tr.local_loss(batch).backward()
+    raised = False
+    try:
+        tr.local_loss(batch).backward()
+    except RuntimeError as e:
+        raised = "one backward per allreduce_and_step" in str(e)
+    assert raised, "a second backward with all-reduces in flight must be refused"
+    # (b) the failed step is abandoned; step() waits for what is in flight, re-arms, and trains
+    l1 = tr.step(batch)
+    assert np.isfinite(l1)
+    # (c) accumulation: three micro-batches, the first two under no_sync()
+    ref = _make_trainer(world)
+    for p, q in zip(ref.params, tr.params):
+        p.data.copy_(q.data)
+    micro = [make_scene_batch([rank], N_POINTS, CFG["image_size"], "cpu", seed=10 + k) for k in range(3)]
+    tr._arm_units(); tr.flat_grad.zero_()
+    with tr.no_sync():
+        tr.local_loss(micro[0]).backward()
+        tr.local_loss(micro[1]).backward()
+        assert all(u["work"] is None for u in tr.units), "no collective may start under no_sync()"
+        g_acc = tr.flat_grad.clone()                      # (nothing in flight: safe to read)
+    tr.local_loss(micro[2]).backward()                    # the pass that completes the accumulation launches the units
+    assert all(u["work"] is not None for u in tr.units)
+    tr.allreduce_and_step()
+    ref._arm_units(); ref.flat_grad.zero_()
+    with ref.no_sync():
+        (ref.local_loss(micro[0]) + ref.local_loss(micro[1])).backward()
+        g_ref = ref.flat_grad.clone()
+    flat = torch.cat([p.detach().reshape(-1) for p in tr.params])
+    torch.save(dict(flat=flat, g_acc=g_acc, g_ref=g_ref), os.path.join(out_dir, f"guard{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_hooks_refuse_a_second_backward_and_no_sync_accumulates(tmp_path):
+    port = _free_port()
+    mp.spawn(_guard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f"guard{k}.pt") for k in range(2)]
+    assert torch.equal(r[0]["flat"], r[1]["flat"])                    # replicas agree after the failed + the accumulated step
+    for k in range(2):                                                # two accumulated passes == one backward of the sum
+        assert float(r[k]["g_ref"].abs().max()) > 0
+        assert torch.allclose(r[k]["g_acc"], r[k]["g_ref"], rtol=1e-4, atol=1e-9)
+
+
 def test_decoder_shapes_and_param_count():
     d = SequentialDecoderReverse()
     assert sum(p.numel() for p in d.parameters()) == 193294     # SURVEY.md 2c: "decoder ~0.194 M params"
@@ -184,3 +242,10 @@ def test_allreduce_payload_of_the_full_configuration():
     # every parameter belongs to at least one unit, and a unit waits for exactly the parameters that overlap it
     assert all(len(tr._units_of_param[id(p)]) >= 1 for p in tr.params)
     assert sum(u["need"] for u in tr.units) == sum(len(v) for v in tr._units_of_param.values())
+    # the same payload in the form BASELINE config 3 / 5 name: PanoHead tri-grids [3, 96, 256, 256], the stand-in holds the rest
+    del tr
+    tr = DecoderTrainer("cpu", n_scenes_total=1, render_fn=render_simple_cpu, loss_fn=image_loss_torch,
+                        plane_axes="panohead", triplane_depth=3, backbone_params=29_570_000 - 3 * 96 * 256 * 256)
+    assert tuple(tr.planes.shape) == (3, 96, 256, 256) and tr.decoder.triplane_depth == 3
+    assert sum(p.numel() for p in tr.params) == 29_763_294
+    assert sum(u["end"] - u["start"] for u in tr.units) == 29_763_294
