@@ -150,6 +150,7 @@ extern "C" void ggd_destroy(ggd_ctx* ctx) {
   if (ctx->d_words) (void)hipFree(ctx->d_words);
   if (ctx->h_words) (void)hipHostFree(ctx->h_words);
   if (ctx->sortctl) (void)hipFree(ctx->sortctl);
+  if (ctx->gelu_tables) (void)hipFree(ctx->gelu_tables);
   if (ctx->scan_sums) (void)hipFree(ctx->scan_sums);
   if (ctx->stats_buf) (void)hipFree(ctx->stats_buf);
   if (ctx->dbg_keys) (void)hipFree(ctx->dbg_keys);

@@ -40,6 +40,7 @@ struct ggd_ctx {
   uint32_t* scan_sums = nullptr;    // block sums of a scan that rides on the depth sort (own allocation, grow-only)
   int scan_sums_cap = 0;
   bool scan_deferred = false;       // geometry_enqueue left the scan to the sort launches of the same call
+  void* gelu_tables = nullptr;      // GELU / GELU' interpolation tables of the reference-precision decoder kernels (built on first use)
   uint32_t r_tag = 0;               // sequence number of the single-call forward whose num_rendered the host is waiting for
   bool r_pending = false;           // the host waits for the tagged word (h_words[2..3]), not for the end of the frame
   void* dbg_keys = nullptr;     // debug copy of the unsorted list

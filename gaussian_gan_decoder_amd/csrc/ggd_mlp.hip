@@ -537,6 +537,13 @@ extern "C" int ggd_decoder_pack_hl(ggd_ctx* ctx, void* stream, const float* cons
 
 static int hl_attributes(ggd_ctx* ctx) {
   if (ctx->attr_mask & GGD_ATTR_MLP_HL) return GGD_OK;
+  // the GELU / GELU' tables (ggd_mlp_wgrad.inc), built once per context in double precision
+  if (!ctx->gelu_tables) {
+    GGD_HIP(hipMalloc(&ctx->gelu_tables, GT_BYTES));
+    hipLaunchKernelGGL(hl_tables_kernel, dim3((GT_N_BWD + 256) / 256), dim3(256), 0, nullptr, static_cast<unsigned char*>(ctx->gelu_tables));
+    GGD_HIP(hipGetLastError());
+    GGD_HIP(hipStreamSynchronize(nullptr));
+  }
   GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_forward_hl_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)HL_LDS_FWD));
   GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_forward_hl_kernel<true>),
@@ -544,7 +551,7 @@ static int hl_attributes(ggd_ctx* ctx) {
   GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_backward_hl_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)HL_LDS_BWD));
   GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_wgrad_hl_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WGH_LDS));
   ctx->attr_mask |= GGD_ATTR_MLP_HL;
   return GGD_OK;
 }
@@ -562,11 +569,11 @@ extern "C" int ggd_decoder_forward_hl(ggd_ctx* ctx, void* stream, const float* f
   if (zbuf)
     hipLaunchKernelGGL(decoder_forward_hl_kernel<true>, dim3(grid), dim3(FWD_THREADS), HL_LDS_FWD,
                        static_cast<hipStream_t>(stream), feat, pos, N, static_cast<const unsigned char*>(packed_hl), attrs,
-                       static_cast<__bf16*>(zbuf));
+                       static_cast<__bf16*>(zbuf), static_cast<const unsigned char*>(ctx->gelu_tables));
   else
     hipLaunchKernelGGL(decoder_forward_hl_kernel<false>, dim3(grid), dim3(FWD_THREADS), HL_LDS_FWD,
                        static_cast<hipStream_t>(stream), feat, pos, N, static_cast<const unsigned char*>(packed_hl), attrs,
-                       (__bf16*)nullptr);
+                       (__bf16*)nullptr, static_cast<const unsigned char*>(ctx->gelu_tables));
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }
@@ -601,12 +608,14 @@ extern "C" int ggd_decoder_backward_wgrad_hl(ggd_ctx* ctx, void* stream, int32_t
     if (grid > 256) grid = 256;
     hipLaunchKernelGGL(decoder_backward_hl_kernel, dim3(grid), dim3(MLP_THREADS), HL_LDS_BWD, s, N, first, last,
                        static_cast<const unsigned char*>(packed_t_hl), attrs, dattrs, static_cast<const __bf16*>(zbuf),
-                       static_cast<__bf16*>(dzbuf), dout, dfeat, dinfo, karr, kref);
+                       static_cast<__bf16*>(dzbuf), dout, dfeat, dinfo, karr, kref,
+                       static_cast<const unsigned char*>(ctx->gelu_tables));
     int chunks = (n + 4 * WG_K - 1) / (4 * WG_K);
     if (chunks > 128) chunks = 128;
     if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL(decoder_wgrad_hl_kernel, dim3(chunks, NHEAD * 4), dim3(WG_THREADS), WG_LDS, s, N, first, last,
-                       static_cast<const __bf16*>(zbuf), static_cast<const __bf16*>(dzbuf), dout, feat, pos, attrs, wgrad, karr, kref);
+    hipLaunchKernelGGL(decoder_wgrad_hl_kernel, dim3(chunks, NHEAD * 4), dim3(WG_THREADS), WGH_LDS, s, N, first, last,
+                       static_cast<const __bf16*>(zbuf), static_cast<const __bf16*>(dzbuf), dout, feat, pos, attrs, wgrad, karr, kref,
+                       static_cast<const unsigned char*>(ctx->gelu_tables));
   }
   GGD_HIP(hipGetLastError());
   return GGD_OK;
