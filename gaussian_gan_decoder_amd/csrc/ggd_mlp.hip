@@ -57,6 +57,8 @@ constexpr int SLAB = 32;  // points per wave iteration (two 16-point MFMA column
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 
+#include "ggd_mlp_gelu.inc"
+
 // Two GELUs per call, transcendental-free and packed (v_pk_fma_f32): x * Phi(x) with
 // Phi(x) ~= 0.5 + xc * P7(xc^2), xc = clamp(x, -4, 4) (least-squares fit on Chebyshev nodes; max |Phi error| 4.9e-5,
 // max |GELU error| 2e-4 on [-4, 4] and 4.9e-5 * |x| beyond -- an order below the bf16 rounding the activation gets
@@ -144,6 +146,9 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* __restrict__ w, 
   }
 }
 
+// (The LDS-table GELU of the reference-precision kernels, ggd_mlp_gelu.inc, was measured here too: 0.924 against 0.772 ms at
+// 1 M points -- the packed polynomial's 11 issue slots per value come as 6 instructions and need no LDS round trip inside a
+// kernel whose LDS port is busy with weight fragments; it stays.)
 __device__ __forceinline__ void gelu_pack(const f4 (&acc)[2][8], bf16x8 (&bout)[2][4]) {
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -328,6 +333,16 @@ extern "C" int ggd_decoder_pack(ggd_ctx* ctx, void* stream, const float* const* 
   hipLaunchKernelGGL(decoder_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), ptrs,
                      static_cast<unsigned char*>(packed), static_cast<unsigned char*>(packed_t));
   GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
+// the GELU / GELU' tables (ggd_mlp_gelu.inc), built once per context in double precision
+static int gelu_tables(ggd_ctx* ctx) {
+  if (ctx->gelu_tables) return GGD_OK;
+  GGD_HIP(hipMalloc(&ctx->gelu_tables, GT_BYTES));
+  hipLaunchKernelGGL(hl_tables_kernel, dim3((GT_N_BWD + 256) / 256), dim3(256), 0, nullptr, static_cast<unsigned char*>(ctx->gelu_tables));
+  GGD_HIP(hipGetLastError());
+  GGD_HIP(hipStreamSynchronize(nullptr));
   return GGD_OK;
 }
 
@@ -537,13 +552,7 @@ extern "C" int ggd_decoder_pack_hl(ggd_ctx* ctx, void* stream, const float* cons
 
 static int hl_attributes(ggd_ctx* ctx) {
   if (ctx->attr_mask & GGD_ATTR_MLP_HL) return GGD_OK;
-  // the GELU / GELU' tables (ggd_mlp_wgrad.inc), built once per context in double precision
-  if (!ctx->gelu_tables) {
-    GGD_HIP(hipMalloc(&ctx->gelu_tables, GT_BYTES));
-    hipLaunchKernelGGL(hl_tables_kernel, dim3((GT_N_BWD + 256) / 256), dim3(256), 0, nullptr, static_cast<unsigned char*>(ctx->gelu_tables));
-    GGD_HIP(hipGetLastError());
-    GGD_HIP(hipStreamSynchronize(nullptr));
-  }
+  { const int rt = gelu_tables(ctx); if (rt != GGD_OK) return rt; }
   GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_forward_hl_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)HL_LDS_FWD));
   GGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_forward_hl_kernel<true>),
