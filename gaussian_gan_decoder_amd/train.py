@@ -255,6 +255,8 @@ class DecoderTrainer:
         u["work"] = self.dist.all_reduce(self.flat_grad[u["start"]:u["end"]], op=self.dist.ReduceOp.SUM, group=self.pg,
                                          async_op=True)
         self._launched_bytes += (u["end"] - u["start"]) * 4
+        self._launch_seq = getattr(self, "_launch_seq", 0) + 1
+        u["seq"] = self._launch_seq
 
     def _grad_ready(self, p):
         if getattr(self, "_defer", False):
@@ -280,7 +282,15 @@ class DecoderTrainer:
                 if u["work"] is None:
                     self._launch_unit(u)
         stalls = []
-        for k, (s, e, _) in enumerate(self.buckets):
+        # buckets in the order their LAST unit was launched (the same on every rank: hooks fire in the autograd graph's order):
+        # the backbone's gradient was final -- and its all-reduce launched -- at the start of the backward, the planes' and
+        # the decoder's at its very end, so the backbone buckets' Adam runs while the late units are still travelling
+        order = list(range(len(self.buckets)))
+        if multi:
+            last = {k: max(u.get("seq", 0) for u in self.units if u["bucket"] == k) for k in order}
+            order.sort(key=lambda k: last[k])
+        for k in order:
+            s, e, _ = self.buckets[k]
             g = self.flat_grad[s:e]
             if multi:
                 for u in self.units:
