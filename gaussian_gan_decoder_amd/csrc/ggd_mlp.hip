@@ -7,14 +7,15 @@
 // every head seeing [plane_mean(32), position(3), outputs of the earlier heads].
 //
 // Formulation: TRANSPOSED GEMMs, Y^T[feature][point] = W[feature][k] . X^T[k][point], with
-// v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  The C/D layout of one layer (lane = point column, 4 consecutive
+// v_mfma_f32_16x16x32_f16 (fp32 accumulate; f16 operands in the forward since round 4 -- 11 significant bits instead of
+// bf16's 8 at the same MFMA rate, and a GELU that runs in packed f16; the backward kernels keep bf16 for dz's range).  The C/D layout of one layer (lane = point column, 4 consecutive
 // feature rows per lane group) IS a valid B-operand layout of the next layer, so activations never leave registers
 // between layers: no LDS round trip, no transposes.  (The MFMA pairs element e of lane (i,g) in A with element e
 // of lane (j,g) in B, so any assignment of k to (g,e) is legal as long as A and B agree; the weight rows are
-// pre-permuted on the host to the order the D layout produces.)  Weights of ONE head (86 KiB bf16, 16-byte slots
+// pre-permuted on the host to the order the D layout produces.)  Weights of ONE head (86 KiB of 16-bit values, 16-byte slots
 // XOR-swizzled by the row so that the ds_read_b128 lane groups are bank-conflict free) are resident in LDS; a 512-thread workgroup
 // (8 waves: two per SIMD, one in its MFMA phase while the other does its GELUs) walks 32-point slabs.
-// GELU is x * Phi(x) with a transcendental-free polynomial Phi (|GELU err| <= 2e-4 on [-4, 4], below bf16 resolution).
+// GELU: transcendental-free polynomials -- forward in packed f16 (gelu_h2x4), weight-gradient recompute in packed fp32 (gelu2x4).
 #include "ggd_common.h"
 
 namespace {
@@ -59,6 +60,7 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 
 #include "ggd_mlp_gelu.inc"
 
+// fp32 form (the weight-gradient kernel recomputes a = gelu(z) with it; the forward used it until round 4).
 // Two GELUs per call, transcendental-free and packed (v_pk_fma_f32): x * Phi(x) with
 // Phi(x) ~= 0.5 + xc * P7(xc^2), xc = clamp(x, -4, 4) (least-squares fit on Chebyshev nodes; max |Phi error| 4.9e-5,
 // max |GELU error| 2e-4 on [-4, 4] and 4.9e-5 * |x| beyond -- an order below the bf16 rounding the activation gets
@@ -110,34 +112,86 @@ __device__ __forceinline__ bf16x8 pack8(const f4& lo, const f4& hi) {
   return r;
 }
 
+// ---- forward operands: f16 (weights and activations), v_mfma_f32_16x16x32_f16
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+
+// Four GELU pairs in packed f16, in lock step:
+//   gelu(x) = max(x, 0) - u q(v),   u = min(|x|, 4),  v = u / 2 - 1,   q(v) ~ Q(u) = 1 - Phi(u) on [0, 4]
+// q = degree-6 Chebyshev interpolant in the monomial basis of v in [-1, 1] (sum |c_k| = 0.73: a Horner chain in f16 loses
+// nothing to cancellation, whereas Phi = 0.5 + x P(x^2) has alternating coefficients up to 13 and is off by 1.5e-2 in f16).
+// Error over EVERY f16 x (scripts/gelu_f16_fit.py evaluates the chain with the kernel's roundings): <= 1.7e-3 for
+// 2 <= x < 4 (9.8e-4 of it is the f16 rounding of the result; a bf16 result is off by 7.8e-3 there), <= 7.7e-4 elsewhere,
+// mean 5e-5.  x = -inf gives -4 q(1) = -1.9e-4; a pre-activation beyond +65504 stays +inf (the reference-precision kernels
+// clamp; this tier does not spend two instructions per pair on it).  12 instructions per pair, conversion included.
+// Measured against the fp32 form above at 1 M points (profiles/r04/decoder_forward_f16.txt): kernel 905 -> 798 us, error of
+// the decoded attributes against the fp32 module 1.2e-3 -> 3.6e-4 max, 1.4e-4 -> 3.5e-5 mean.  Degree 8: 850 us / 2.4e-4;
+// degree 5: 775 us / 6.2e-4.  Every v_pk_*_f16 and v_cvt_pk_* costs 4.2 cycles of a SIMD, v_pk_*_f32 4.6, plain fp32 2.5
+// (scripts/probes/f16_rate_probe.hip): the gain is the instruction count (12 against 13 per pair at 1.85 slots each plus
+// two med3), not a faster pipe.  Like v_pk_*_f32, a v_pk_*_f16 that reads the previous packed result needs a wait state:
+// left alone the compiler runs the four chains of a 16-byte piece one after the other with an s_nop behind every step
+// (929 per slab and head; 67 in lock step).
+__device__ __forceinline__ void gelu_h2x4(h2v (&x)[4]) {
+  constexpr int DEG = 6;
+  constexpr float C[DEG + 1] = {2.275013195e-02f, -1.085930641e-01f, 2.184360610e-01f, -2.120909633e-01f,
+                                5.175106045e-02f, 7.087319211e-02f, -4.320753570e-02f};
+  h2v u[4], v[4], q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = __builtin_elementwise_abs(x[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = __builtin_elementwise_min(u[i], (h2v){4.0f16, 4.0f16});
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = __builtin_elementwise_fma(u[i], (h2v){0.5f16, 0.5f16}, (h2v){-1.0f16, -1.0f16});
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = __builtin_elementwise_max(x[i], (h2v){0.0f16, 0.0f16});
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    q[i] = __builtin_elementwise_fma(v[i], (h2v){(_Float16)C[DEG], (_Float16)C[DEG]}, (h2v){(_Float16)C[DEG - 1], (_Float16)C[DEG - 1]});
+#pragma unroll
+  for (int k = DEG - 2; k >= 0; --k) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = __builtin_elementwise_fma(q[i], v[i], (h2v){(_Float16)C[k], (_Float16)C[k]});
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = __builtin_elementwise_fma(-u[i], q[i], x[i]);
+}
+__device__ __forceinline__ h2v cvt_h2(float a, float b) { return __builtin_convertvector((f2v){a, b}, h2v); }   // v_cvt_pk_f16_f32
+// the kernel's inputs (plane features, positions, earlier heads' outputs) are clamped to the f16 range
+__device__ __forceinline__ float clamp_h(float v) { return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
+__device__ __forceinline__ h16x8 pack8h(const f4& lo, const f4& hi) {
+  const h2v p0 = cvt_h2(clamp_h(lo[0]), clamp_h(lo[1])), p1 = cvt_h2(clamp_h(lo[2]), clamp_h(lo[3]));
+  const h2v p2 = cvt_h2(clamp_h(hi[0]), clamp_h(hi[1])), p3 = cvt_h2(clamp_h(hi[2]), clamp_h(hi[3]));
+  return (h16x8){p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+}
+
 // One hidden layer for the wave's two 16-point column tiles: acc[c][mt] (8 feature tiles x 2 point tiles).
 template <int KB /* 32-wide k blocks */, int ROW>
 __device__ __forceinline__ void layer_mfma(const unsigned char* __restrict__ w, const float* __restrict__ bias,
-                                           const bf16x8 (&bin)[2][4], f4 (&acc)[2][8], int lane) {
+                                           const h16x8 (&bin)[2][4], f4 (&acc)[2][8], int lane) {
   const int i = lane & 15, g = lane >> 4;
   // The weight fragments of feature tile mt + 1 are requested from LDS before the MFMAs of tile mt are issued (one tile of
   // look-ahead, KB extra 16-byte registers): with the reads and their MFMAs in the same scheduling region every tile
   // waited out the LDS latency (~200 cycles x 8 tiles x 3 layers per slab and head).
-  bf16x8 a_cur[KB], a_nxt[KB];
+  h16x8 a_cur[KB], a_nxt[KB];
   f4 b_cur, b_nxt;
   {
 #pragma unroll
-    for (int s = 0; s < KB; ++s) a_cur[s] = *reinterpret_cast<const bf16x8*>(w + wslot<ROW>(i, g + 4 * s));
+    for (int s = 0; s < KB; ++s) a_cur[s] = *reinterpret_cast<const h16x8*>(w + wslot<ROW>(i, g + 4 * s));
     b_cur = *reinterpret_cast<const f4*>(bias + 4 * g);
   }
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     if (mt + 1 < 8) {
 #pragma unroll
-      for (int s = 0; s < KB; ++s) a_nxt[s] = *reinterpret_cast<const bf16x8*>(w + wslot<ROW>(16 * (mt + 1) + i, g + 4 * s));
+      for (int s = 0; s < KB; ++s) a_nxt[s] = *reinterpret_cast<const h16x8*>(w + wslot<ROW>(16 * (mt + 1) + i, g + 4 * s));
       b_nxt = *reinterpret_cast<const f4*>(bias + 16 * (mt + 1) + 4 * g);
     }
     __builtin_amdgcn_sched_barrier(0);
     acc[0][mt] = b_cur; acc[1][mt] = b_cur;   // D rows 4g..4g+3 of this feature tile start from the bias
 #pragma unroll
     for (int s = 0; s < KB; ++s) {
-      acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[s], bin[0][s], acc[0][mt], 0, 0, 0);
-      acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[s], bin[1][s], acc[1][mt], 0, 0, 0);
+      acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[s], bin[0][s], acc[0][mt], 0, 0, 0);
+      acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[s], bin[1][s], acc[1][mt], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the reads of later tiles from being hoisted further (VGPR pressure)
 #pragma unroll
@@ -146,24 +200,18 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* __restrict__ w, 
   }
 }
 
-// (The LDS-table GELU of the reference-precision kernels, ggd_mlp_gelu.inc, was measured here too: 0.924 against 0.772 ms at
-// 1 M points -- the packed polynomial's 11 issue slots per value come as 6 instructions and need no LDS round trip inside a
-// kernel whose LDS port is busy with weight fragments; it stays.)
-__device__ __forceinline__ void gelu_pack(const f4 (&acc)[2][8], bf16x8 (&bout)[2][4]) {
+// (The LDS-table GELU of the reference-precision kernels, ggd_mlp_gelu.inc, was measured here too, against the fp32 polynomial:
+// 0.924 against 0.772 ms at 1 M points -- no LDS round trip fits inside a kernel whose LDS port is busy with weight fragments.)
+__device__ __forceinline__ void gelu_pack(const f4 (&acc)[2][8], h16x8 (&bout)[2][4]) {
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      f4 lo, hi;
-      {
-        const f4& a0 = acc[c][2 * s];
-        const f4& a1 = acc[c][2 * s + 1];
-        f2v gx[4] = {(f2v){a0[0], a0[1]}, (f2v){a0[2], a0[3]}, (f2v){a1[0], a1[1]}, (f2v){a1[2], a1[3]}};
-        gelu2x4(gx);
-        lo = (f4){gx[0].x, gx[0].y, gx[1].x, gx[1].y};
-        hi = (f4){gx[2].x, gx[2].y, gx[3].x, gx[3].y};
-      }
-      bout[c][s] = pack8(lo, hi);
+      const f4& a0 = acc[c][2 * s];
+      const f4& a1 = acc[c][2 * s + 1];
+      h2v p[4] = {cvt_h2(a0[0], a0[1]), cvt_h2(a0[2], a0[3]), cvt_h2(a1[0], a1[1]), cvt_h2(a1[2], a1[3])};
+      gelu_h2x4(p);
+      bout[c][s] = (h16x8){p[0][0], p[0][1], p[1][0], p[1][1], p[2][0], p[2][1], p[3][0], p[3][1]};
       __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -235,7 +283,7 @@ __global__ __launch_bounds__(FWD_THREADS, FWD_WAVES / 4) void decoder_forward_ke
 
     for (int64_t p0 = cbeg + (int64_t)wv * SLAB; p0 < cend; p0 += (int64_t)FWD_WAVES * SLAB) {
       // ---- inputs: k-block 0 = 32 plane features, k-block 1 = info slots 4g..4g+3 (upper half of the block zero)
-      bf16x8 bin[2][4];
+      h16x8 bin[2][4];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const int64_t pt = p0 + 16 * c + j;
@@ -254,11 +302,11 @@ __global__ __launch_bounds__(FWD_THREADS, FWD_WAVES / 4) void decoder_forward_ke
           }
         }
         const f4 z = {0, 0, 0, 0};
-        bin[c][0] = pack8(lo, hi);
-        bin[c][1] = pack8(inf, z);
+        bin[c][0] = pack8h(lo, hi);
+        bin[c][1] = pack8h(inf, z);
       }
       f4 acc[2][8];
-      bf16x8 bh[2][4];
+      h16x8 bh[2][4];
       layer_mfma<2, ROW1>(wl + OFF_W1, b1, bin, acc, lane);
       if (STORE_Z) store_z(zbuf + (size_t)(head * 3 + 0) * zlayer_elems(N), acc, p0, cend, lane);
       gelu_pack(acc, bh);
@@ -275,9 +323,9 @@ __global__ __launch_bounds__(FWD_THREADS, FWD_WAVES / 4) void decoder_forward_ke
         out[0] = bb; out[1] = bb;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(wl + OFF_W4 + wslot<ROW2>(j, g + 4 * s));
-          out[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh[0][s], out[0], 0, 0, 0);
-          out[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh[1][s], out[1], 0, 0, 0);
+          const h16x8 a = *reinterpret_cast<const h16x8*>(wl + OFF_W4 + wslot<ROW2>(j, g + 4 * s));
+          out[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh[0][s], out[0], 0, 0, 0);
+          out[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh[1][s], out[1], 0, 0, 0);
         }
       }
       // lane group 0 holds output features 0..3 of point j (D rows 0..3)

@@ -1,10 +1,12 @@
-"""Inference-time fused decoder: tri-plane gather + the 5 chained MLP heads as ONE bf16-MFMA kernel
+"""Inference-time fused decoder: tri-plane gather + the 5 chained MLP heads as ONE MFMA kernel with 16-bit operands
 (csrc/ggd_mlp.hip; SURVEY.md section 8f row 1, BASELINE config 3).
 
 `FusedDecoder(decoder)` wraps a `SequentialDecoderReverse` (same parameters; call `.repack()` after they change) and
 returns the same namespace (xyz, scale, rotation, opacity, color).  No autograd: training keeps the PyTorch modules.
-Numerics: weights and activations are rounded to bf16 at every layer input, accumulation / bias / GELU in fp32
-(erf-form GELU with a polynomial erf, |err| < 5.7e-5)."""
+Numerics of the forward: weights and activations are rounded to f16 (11 significant bits; inputs and weights clamped to
++-65504) at every layer input, accumulation and bias in fp32, GELU as a degree-6 polynomial in packed f16 (<= 1.7e-3, mean
+5e-5: scripts/gelu_f16_fit.py).  The training tier named "bf16" runs this forward; its backward kernels keep bf16 operands
+(dz needs the exponent range)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -16,7 +18,7 @@ from . import _capi
 from .decoder import SequentialDecoderReverse, triplane_mean
 
 HID = 128
-ROW1, ROW2 = 64, 128                # bf16 elements per weight row (no padding; 16-byte slots swizzled, see _swizzle_rows)
+ROW1, ROW2 = 64, 128                # 16-bit elements per weight row (no padding; 16-byte slots swizzled, see _swizzle_rows)
 # position (g, e) inside a 32-wide k block  <-  k = 4g+e (e < 4) or 16+4g+(e-4): the order the MFMA C/D layout
 # hands a layer's outputs to the next layer's B operand (csrc/ggd_mlp.hip header)
 _PERM32 = [(4 * g + e) if e < 4 else (16 + 4 * g + (e - 4)) for g in range(4) for e in range(8)]
@@ -62,8 +64,8 @@ def _swizzle_rows(wp: torch.Tensor) -> torch.Tensor:
 
 
 def pack_weights(decoder: SequentialDecoderReverse) -> torch.Tensor:
-    """-> uint8 tensor of ggd_decoder_packed_bytes(): per head [W1 128x64 | W2 128x128 | W3 128x128 | W4 16x128] bf16 (slots
-    swizzled), then b1 b2 b3 [128] and b4 [16] fp32."""
+    """-> uint8 tensor of ggd_decoder_packed_bytes(): per head [W1 128x64 | W2 128x128 | W3 128x128 | W4 16x128] f16 (clamped
+    to +-65504, slots swizzled), then b1 b2 b3 [128] and b4 [16] fp32."""
     _check_decoder(decoder)
     dev = next(decoder.parameters()).device
     chunks = []
@@ -82,7 +84,7 @@ def pack_weights(decoder: SequentialDecoderReverse) -> torch.Tensor:
         for w, row in ((w1, ROW1), (l2.weight.detach().float(), ROW2), (l3.weight.detach().float(), ROW2), (w4, ROW2)):
             assert row == w.shape[1]
             wp = _swizzle_rows(_permute_blocks(w))
-            rows.append(wp.to(torch.bfloat16).contiguous().view(torch.uint8).reshape(-1))
+            rows.append(wp.clamp(-65504.0, 65504.0).to(torch.float16).contiguous().view(torch.uint8).reshape(-1))
         biases = torch.cat([l1.bias.detach().float(), l2.bias.detach().float(), l3.bias.detach().float(), b4])
         chunks += rows + [biases.contiguous().view(torch.uint8).reshape(-1)]
     packed = torch.cat(chunks).contiguous()

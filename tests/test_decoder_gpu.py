@@ -123,14 +123,15 @@ def test_decoder_forward_backward_runs_on_gpu(native_lib):
     assert (out.xyz.detach().cpu() - out_cpu.xyz).abs().max().item() <= 1e-4
 
 
-def _bf16_reference(dec, feats, pos):
-    """PyTorch emulation of the kernel's numerics: every layer input and weight rounded to bf16, fp32 accumulate."""
-    r = lambda t: t.to(torch.bfloat16).float()
+def _f16_reference(dec, feats, pos):
+    """PyTorch emulation of the forward kernel's numerics: every layer input and weight rounded to f16, fp32 accumulate;
+    the pre-activation rounded to f16 before an exact GELU (the kernel's GELU is a polynomial in packed f16)."""
+    r = lambda t: t.to(torch.float16).float()
 
     def mlp(head, x):
         for k in (0, 2, 4):
             lin = head.backbone[k]
-            x = torch.nn.functional.gelu(r(x) @ r(lin.weight).t() + lin.bias)
+            x = torch.nn.functional.gelu(r(r(x) @ r(lin.weight).t() + lin.bias))
         lin = head.backbone[6]
         return r(x) @ r(lin.weight).t() + lin.bias
     info = pos
@@ -157,20 +158,22 @@ def test_fused_decoder_matches_torch(native_lib, N):
     out = fused(planes, pos)
     feats = triplane_mean(planes, pos, 1.0)
     with torch.no_grad():
-        emu = _bf16_reference(dec, feats, pos)
+        emu = _f16_reference(dec, feats, pos)
         ref = dec(planes, pos)
     for name in ("color", "opacity", "rotation", "scale", "xyz"):
         got = getattr(out, name)
         assert got.shape == emu[name].shape, name
-        # tight vs the bf16 emulation (same rounding points; differences = accumulation order + GELU 1.5e-7)
-        assert (got - emu[name]).abs().max().item() <= 2e-3 * max(1.0, emu[name].abs().max().item()), name
-        # loose vs the fp32 module (bf16 has 8 mantissa bits; 4 layers deep)
-        assert (got - getattr(ref, name)).abs().max().item() <= 5e-2 * max(1.0, getattr(ref, name).abs().max().item()), name
+        # vs the f16 emulation (same rounding points; differences = accumulation order + the GELU polynomial, <= 1.7e-3 per
+        # activation, mean 5e-5)
+        assert (got - emu[name]).abs().max().item() <= 1e-3 * max(1.0, emu[name].abs().max().item()), name
+        # vs the fp32 module: f16 operands (11 significant bits), 4 layers deep.  Measured 3.6e-4 max / 3.5e-5 mean at
+        # 1 M points (the bf16 forward of rounds 1-3: 1.2e-3 / 1.4e-4, bound 5e-2)
+        assert (got - getattr(ref, name)).abs().max().item() <= 2e-3 * max(1.0, getattr(ref, name).abs().max().item()), name
 
 
 def test_fused_decoder_training_gradients(native_lib):
-    """FusedTrainDecoder (bf16-MFMA forward + activation backward, split-K weight gradients) vs PyTorch autograd of the
-    fp32 module: outputs and every gradient within bf16-level tolerance."""
+    """FusedTrainDecoder (f16-MFMA forward, bf16-MFMA activation backward, split-K weight gradients) vs PyTorch autograd of
+    the fp32 module: outputs within the f16 forward's bound, every gradient within bf16-level tolerance."""
     from gaussian_gan_decoder_amd.fused_decoder import FusedTrainDecoder
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
@@ -194,7 +197,7 @@ def test_fused_decoder_training_gradients(native_lib):
     ob = fused(planes_b, pos); loss(ob).backward()
     for k in w:
         a, b = getattr(oa, k), getattr(ob, k)
-        assert (a - b).abs().max().item() <= 5e-2 * max(1.0, a.abs().max().item()), k
+        assert (a - b).abs().max().item() <= 2e-3 * max(1.0, a.abs().max().item()), k
 
     def rel(a, b):
         return ((a - b).norm() / (a.norm() + 1e-12)).item()
@@ -205,8 +208,8 @@ def test_fused_decoder_training_gradients(native_lib):
 
 
 def test_fused_decoder_matches_reference_class_fixture(native_lib):
-    """The fused bf16-MFMA decoder against the outputs of the reference's own SequentialDecoderReverse
-    (tests/golden/sequential_decoder_fixture.npz, fp32): bf16 operand rounding bounds the error (5e-2 of the output
+    """The fused f16-MFMA decoder against the outputs of the reference's own SequentialDecoderReverse
+    (tests/golden/sequential_decoder_fixture.npz, fp32): f16 operand rounding bounds the error (2e-3 of the output
     scale); the fp32 PyTorch path on the GPU must match it to 2e-5."""
     import os
     import numpy as np
@@ -224,7 +227,7 @@ def test_fused_decoder_matches_reference_class_fixture(native_lib):
         ref = f[k]
         np.testing.assert_allclose(getattr(o32, k).cpu().numpy(), ref, atol=2e-5, rtol=1e-5, err_msg=k)
         scale = max(1.0, float(np.abs(ref).max()))
-        assert float(np.abs(getattr(o16, k).cpu().numpy() - ref).max()) <= 5e-2 * scale, k
+        assert float(np.abs(getattr(o16, k).cpu().numpy() - ref).max()) <= 2e-3 * scale, k
 
 
 def test_device_pack_matches_the_host_statement_of_the_format(native_lib):
@@ -262,13 +265,13 @@ def test_fused_train_decoder_follows_an_optimizer_step(native_lib):
         ref = mod(planes, pos).color
         now = fused(planes, pos).color
     assert (outs[1] - outs[0]).abs().max().item() > 1e-3 and (outs[2] - outs[1]).abs().max().item() > 1e-3
-    assert (now - ref).abs().max().item() <= 5e-2 * max(1.0, ref.abs().max().item())
+    assert (now - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("N", [1, 33, 5000, 100003, 1_000_000])
 def test_fused_decoder_fp32_precision_matches_the_fp32_module(native_lib, N):
     """precision="fp32" (split bf16 operands, three MFMAs per product, csrc/ggd_mlp_hl.inc): every output within 1e-4 of the
-    fp32 PyTorch module (the bf16 form is only held to 5e-2) -- the reference trains and evaluates its decoder in fp32
+    fp32 PyTorch module (the f16 fast form is held to 2e-3) -- the reference trains and evaluates its decoder in fp32
     (main/decoder_models/base_decoder.py:8-27)."""
     from gaussian_gan_decoder_amd.fused_decoder import FusedDecoder
     dev = torch.device("cuda:0")
@@ -294,7 +297,7 @@ def test_fused_decoder_fp32_precision_matches_the_fp32_module(native_lib, N):
 
 def test_fused_decoder_fp32_precision_matches_reference_class_fixture(native_lib):
     """precision="fp32" against the outputs of the reference's own SequentialDecoderReverse (fp32; sequential_decoder_fixture.npz):
-    1e-4 (the fp32 PyTorch path on the GPU is held to 2e-5, the bf16 kernel to 5e-2)."""
+    1e-4 (the fp32 PyTorch path on the GPU is held to 2e-5, the f16 fast kernel to 2e-3)."""
     import os
     import numpy as np
     from gaussian_gan_decoder_amd.fused_decoder import FusedDecoder

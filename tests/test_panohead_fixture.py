@@ -51,7 +51,7 @@ def test_panohead_decoder_forward_matches_reference_on_cpu():
 @pytest.mark.gpu
 def test_panohead_decoder_forward_matches_reference_on_gpu(native_lib):
     """Same fixture through the HIP tri-grid gather (ggd_trigrid_forward) + the fp32 module (<= 2e-5) and through the
-    fused bf16-MFMA decoder (<= 5e-2); the gather's backward against torch's grid_sample autograd."""
+    fused f16-MFMA decoder (<= 2e-3); the gather's backward against torch's grid_sample autograd."""
     from gaussian_gan_decoder_amd.fused_decoder import FusedDecoder
     f, planes, pos, dec, depth = _load()
     dev = torch.device("cuda:0")
@@ -64,7 +64,7 @@ def test_panohead_decoder_forward_matches_reference_on_gpu(native_lib):
         fused = FusedDecoder(dec_d)(planes_d, pos_d)
     for h in HEADS:
         assert np.abs(getattr(out, h).cpu().numpy() - f[h]).max() <= 2e-5, h
-        assert np.abs(getattr(fused, h).float().cpu().numpy() - f[h]).max() <= 5e-2, h
+        assert np.abs(getattr(fused, h).float().cpu().numpy() - f[h]).max() <= 2e-3 * max(1.0, float(np.abs(f[h]).max())), h
     # backward of the gather (scatter-add into the tri-grids) vs autograd through grid_sample, on the window region
     g = torch.Generator().manual_seed(3)
     dout = torch.randn(pos.shape[0], 32, generator=g)
