@@ -116,44 +116,45 @@ __device__ __forceinline__ bf16x8 pack8(const f4& lo, const f4& hi) {
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
-// Four GELU pairs in packed f16, in lock step:
-//   gelu(x) = max(x, 0) - u q(v),   u = min(|x|, 4),  v = u / 2 - 1,   q(v) ~ Q(u) = 1 - Phi(u) on [0, 4]
-// q = degree-6 Chebyshev interpolant in the monomial basis of v in [-1, 1] (sum |c_k| = 0.73: a Horner chain in f16 loses
-// nothing to cancellation, whereas Phi = 0.5 + x P(x^2) has alternating coefficients up to 13 and is off by 1.5e-2 in f16).
-// Error over EVERY f16 x (scripts/gelu_f16_fit.py evaluates the chain with the kernel's roundings): <= 1.7e-3 for
-// 2 <= x < 4 (9.8e-4 of it is the f16 rounding of the result; a bf16 result is off by 7.8e-3 there), <= 7.7e-4 elsewhere,
-// mean 5e-5.  x = -inf gives -4 q(1) = -1.9e-4; a pre-activation beyond +65504 stays +inf (the reference-precision kernels
-// clamp; this tier does not spend two instructions per pair on it).  12 instructions per pair, conversion included.
-// Measured against the fp32 form above at 1 M points (profiles/r04/decoder_forward_f16.txt): kernel 905 -> 798 us, error of
-// the decoded attributes against the fp32 module 1.2e-3 -> 3.6e-4 max, 1.4e-4 -> 3.5e-5 mean.  Degree 8: 850 us / 2.4e-4;
-// degree 5: 775 us / 6.2e-4.  Every v_pk_*_f16 and v_cvt_pk_* costs 4.2 cycles of a SIMD, v_pk_*_f32 4.6, plain fp32 2.5
-// (scripts/probes/f16_rate_probe.hip): the gain is the instruction count (12 against 13 per pair at 1.85 slots each plus
-// two med3), not a faster pipe.  Like v_pk_*_f32, a v_pk_*_f16 that reads the previous packed result needs a wait state:
+// Four GELU pairs in packed f16, in lock step.  The hidden layers' weights and biases are HALVED in the forward image (an exact
+// scaling), so the accumulators hold y = z / 2 and
+//   gelu(z) = z / 2 + |z| (1/2 - Q(|z|)) = y + a s(v),   a = |y|,  v = min(a, 2) - 1,   s(v) ~ 1 - 2 Q(2 (v + 1)),  Q = 1 - Phi
+// s = degree-6 polynomial in the monomial basis of v in [-1, 1] (all partial sums O(1): a Horner chain in f16 loses nothing to
+// cancellation, whereas Phi = 0.5 + x P(x^2) has alternating coefficients up to 13 and is off by 1.5e-2 in f16), minimax fit
+// under s(1) = 1: beyond |z| = 4 the result is z or 0 whatever |z| (scripts/gelu_f16_fit.py: fit, and the error of THIS
+// instruction sequence with its roundings over every f16 value: <= 1.54e-3 for 2 <= z < 4 -- 9.8e-4 of it is the f16 rounding
+// of the result; a bf16 result is off by 7.8e-3 there -- <= 8.8e-4 elsewhere, mean 7e-5).  A pre-activation beyond +-131008
+// becomes +-inf (the reference-precision kernels clamp; this tier does not spend two instructions per pair on it).
+// 11 instructions per pair, conversion included: cvt, and, min, add, 6 fma, fma.
+// Measured at 1 M points (profiles/r04/decoder_forward_f16.txt), against the packed-fp32 Phi polynomial on bf16 operands of
+// rounds 1-3: kernel 905 -> 798 us with the z-form of this polynomial (12 instructions), error of the decoded attributes
+// against the fp32 module 1.2e-3 -> 3.6e-4 max, 1.4e-4 -> 3.5e-5 mean; degree 8: 850 us / 2.4e-4; degree 5: 775 us / 6.2e-4.
+// Every v_pk_*_f16 and v_cvt_pk_* costs 4.2 cycles of a SIMD, v_pk_*_f32 4.6, plain fp32 2.5
+// (scripts/probes/f16_rate_probe.hip): the gain is the instruction count (13 packed-fp32 instructions and two med3 per
+// pair before), not a faster pipe.  Like v_pk_*_f32, a v_pk_*_f16 that reads the previous packed result needs a wait state:
 // left alone the compiler runs the four chains of a 16-byte piece one after the other with an s_nop behind every step
 // (929 per slab and head; 67 in lock step).
-__device__ __forceinline__ void gelu_h2x4(h2v (&x)[4]) {
+__device__ __forceinline__ void gelu_h2x4(h2v (&y)[4]) {
   constexpr int DEG = 6;
-  constexpr float C[DEG + 1] = {2.275013195e-02f, -1.085930641e-01f, 2.184360610e-01f, -2.120909633e-01f,
-                                5.175106045e-02f, 7.087319211e-02f, -4.320753570e-02f};
-  h2v u[4], v[4], q[4];
+  constexpr float S[DEG + 1] = {9.546607429e-01f, 2.169445321e-01f, -4.391409802e-01f, 4.247604060e-01f,
+                                -9.772952171e-02f, -1.414002710e-01f, 8.190509189e-02f};
+  h2v a[4], v[4], p[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) u[i] = __builtin_elementwise_abs(x[i]);
+  for (int i = 0; i < 4; ++i) a[i] = __builtin_elementwise_abs(y[i]);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) u[i] = __builtin_elementwise_min(u[i], (h2v){4.0f16, 4.0f16});
+  for (int i = 0; i < 4; ++i) v[i] = __builtin_elementwise_min(a[i], (h2v){2.0f16, 2.0f16});
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = __builtin_elementwise_fma(u[i], (h2v){0.5f16, 0.5f16}, (h2v){-1.0f16, -1.0f16});
-#pragma unroll
-  for (int i = 0; i < 4; ++i) x[i] = __builtin_elementwise_max(x[i], (h2v){0.0f16, 0.0f16});
+  for (int i = 0; i < 4; ++i) v[i] = v[i] - (h2v){1.0f16, 1.0f16};
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    q[i] = __builtin_elementwise_fma(v[i], (h2v){(_Float16)C[DEG], (_Float16)C[DEG]}, (h2v){(_Float16)C[DEG - 1], (_Float16)C[DEG - 1]});
+    p[i] = __builtin_elementwise_fma(v[i], (h2v){(_Float16)S[DEG], (_Float16)S[DEG]}, (h2v){(_Float16)S[DEG - 1], (_Float16)S[DEG - 1]});
 #pragma unroll
   for (int k = DEG - 2; k >= 0; --k) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = __builtin_elementwise_fma(q[i], v[i], (h2v){(_Float16)C[k], (_Float16)C[k]});
+    for (int i = 0; i < 4; ++i) p[i] = __builtin_elementwise_fma(p[i], v[i], (h2v){(_Float16)S[k], (_Float16)S[k]});
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) x[i] = __builtin_elementwise_fma(-u[i], q[i], x[i]);
+  for (int i = 0; i < 4; ++i) y[i] = __builtin_elementwise_fma(a[i], p[i], y[i]);
 }
 __device__ __forceinline__ h2v cvt_h2(float a, float b) { return __builtin_convertvector((f2v){a, b}, h2v); }   // v_cvt_pk_f16_f32
 // the kernel's inputs (plane features, positions, earlier heads' outputs) are clamped to the f16 range
@@ -202,19 +203,12 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* __restrict__ w, 
 
 // (The LDS-table GELU of the reference-precision kernels, ggd_mlp_gelu.inc, was measured here too, against the fp32 polynomial:
 // 0.924 against 0.772 ms at 1 M points -- no LDS round trip fits inside a kernel whose LDS port is busy with weight fragments.)
-__device__ __forceinline__ void gelu_pack(const f4 (&acc)[2][8], h16x8 (&bout)[2][4]) {
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const f4& a0 = acc[c][2 * s];
-      const f4& a1 = acc[c][2 * s + 1];
-      h2v p[4] = {cvt_h2(a0[0], a0[1]), cvt_h2(a0[2], a0[3]), cvt_h2(a1[0], a1[1]), cvt_h2(a1[2], a1[3])};
-      gelu_h2x4(p);
-      bout[c][s] = (h16x8){p[0][0], p[0][1], p[1][0], p[1][1], p[2][0], p[2][1], p[3][0], p[3][1]};
-      __builtin_amdgcn_sched_barrier(0);
-    }
-}
+// acc = y = z / 2 of the wave's tiles -> the next layer's B operand gelu(z) (f16).  STORE_Z (training): z = y + y is kept for
+// the backward as f16, one 16-byte piece per (point tile, k block) in the blocked Z layout below -- the converted pairs are
+// the ones the GELU starts from, so the store costs one v_pk_add_f16 per pair and no second conversion.
+template <bool STORE_Z>
+__device__ __forceinline__ void gelu_pack(const f4 (&acc)[2][8], h16x8 (&bout)[2][4], _Float16* __restrict__ zl, int64_t p0,
+                                          int64_t cend, int lane);
 
 // D-layout tile set (8 feature tiles x 2 point tiles, fp32) <-> bf16 [point][128] in the "Z layout": lane (j = point, g)
 // holds features 16*mt + 4g + r; inside every 32-feature block the row stores them at position
@@ -232,29 +226,39 @@ __device__ __forceinline__ int64_t zpiece(int64_t pt, int k, int g) {
 }
 __device__ __forceinline__ size_t zlayer_elems(int N) { return (size_t)((N + 15) & ~15) * HID; }   // one (head, layer) plane
 
-__device__ __forceinline__ void store_z(__bf16* __restrict__ zl, const f4 (&acc)[2][8], int64_t p0, int64_t cend,
-                                        int lane) {
+template <bool STORE_Z>
+__device__ __forceinline__ void gelu_pack(const f4 (&acc)[2][8], h16x8 (&bout)[2][4], _Float16* __restrict__ zl, int64_t p0,
+                                          int64_t cend, int lane) {
   const int j = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int64_t pt = p0 + 16 * c + j;
-    if (pt >= cend) continue;
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int k = 0; k < 4; ++k)   // Z layout (zpos): the lane's tiles 2k, 2k+1 as ONE 16-byte piece; 4 lanes = 64 B
-      *reinterpret_cast<bf16x8*>(zl + zpiece(pt, k, g)) = pack8(acc[c][2 * k], acc[c][2 * k + 1]);
-  }
+    for (int s = 0; s < 4; ++s) {
+      const f4& a0 = acc[c][2 * s];
+      const f4& a1 = acc[c][2 * s + 1];
+      h2v p[4] = {cvt_h2(a0[0], a0[1]), cvt_h2(a0[2], a0[3]), cvt_h2(a1[0], a1[1]), cvt_h2(a1[2], a1[3])};
+      if (STORE_Z) {   // Z layout (zpos): the lane's tiles 2s, 2s+1 as ONE 16-byte piece; 4 lanes = 64 B
+        const int64_t pt = p0 + 16 * c + j;
+        const h2v z0 = p[0] + p[0], z1 = p[1] + p[1], z2 = p[2] + p[2], z3 = p[3] + p[3];
+        if (pt < cend)
+          *reinterpret_cast<h16x8*>(zl + zpiece(pt, s, g)) = (h16x8){z0[0], z0[1], z1[0], z1[1], z2[0], z2[1], z3[0], z3[1]};
+      }
+      gelu_h2x4(p);
+      bout[c][s] = (h16x8){p[0][0], p[0][1], p[1][0], p[1][1], p[2][0], p[2][1], p[3][0], p[3][1]};
+      __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // attrs row (16 floats per point): [0..2] color, [3] opacity, [4..7] rotation, [8..10] activated scale,
 // [11..13] xyz, [14..15] unused.  It doubles as the carrier of the earlier heads' outputs between heads: the "info"
 // vector a head sees is [position(3), attrs[0 .. n_extra)] with n_extra = 0, 3, 4, 8, 11.
-// STORE_Z (training): the fp32 pre-activations of the three hidden layers are kept (rounded to bf16) for the backward,
+// STORE_Z (training): the pre-activations of the three hidden layers are kept (rounded to f16) for the backward,
 // zbuf[head][layer][16-point block][4 KB] (blocked Z layout above).
 template <bool STORE_Z>
 __global__ __launch_bounds__(FWD_THREADS, FWD_WAVES / 4) void decoder_forward_kernel(const float* __restrict__ feat,
                                                                          const float* __restrict__ pos, int N,
                                                                          const unsigned char* __restrict__ packed,
-                                                                         float* attrs, __bf16* __restrict__ zbuf) {
+                                                                         float* attrs, _Float16* __restrict__ zbuf) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* wl = smem;  // HEAD_BYTES: weights + biases of one head
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -307,15 +311,13 @@ __global__ __launch_bounds__(FWD_THREADS, FWD_WAVES / 4) void decoder_forward_ke
       }
       f4 acc[2][8];
       h16x8 bh[2][4];
+      _Float16* zh = STORE_Z ? zbuf + (size_t)(head * 3) * zlayer_elems(N) : nullptr;
       layer_mfma<2, ROW1>(wl + OFF_W1, b1, bin, acc, lane);
-      if (STORE_Z) store_z(zbuf + (size_t)(head * 3 + 0) * zlayer_elems(N), acc, p0, cend, lane);
-      gelu_pack(acc, bh);
+      gelu_pack<STORE_Z>(acc, bh, zh, p0, cend, lane);
       layer_mfma<4, ROW2>(wl + OFF_W2, b2, bh, acc, lane);
-      if (STORE_Z) store_z(zbuf + (size_t)(head * 3 + 1) * zlayer_elems(N), acc, p0, cend, lane);
-      gelu_pack(acc, bh);
+      gelu_pack<STORE_Z>(acc, bh, zh + zlayer_elems(N), p0, cend, lane);
       layer_mfma<4, ROW2>(wl + OFF_W3, b3, bh, acc, lane);
-      if (STORE_Z) store_z(zbuf + (size_t)(head * 3 + 2) * zlayer_elems(N), acc, p0, cend, lane);
-      gelu_pack(acc, bh);
+      gelu_pack<STORE_Z>(acc, bh, zh + 2 * zlayer_elems(N), p0, cend, lane);
       // ---- output layer: one feature tile (weight rows >= out_dim are zero)
       f4 out[2];
       {
@@ -413,10 +415,10 @@ static int decoder_forward_impl(ggd_ctx* ctx, void* stream, const float* feat, c
   if (grid < 1) grid = 1;
   if (zbuf)
     hipLaunchKernelGGL(decoder_forward_kernel<true>, dim3(grid), dim3(FWD_THREADS), lds, static_cast<hipStream_t>(stream),
-                       feat, pos, N, static_cast<const unsigned char*>(packed_weights), attrs, static_cast<__bf16*>(zbuf));
+                       feat, pos, N, static_cast<const unsigned char*>(packed_weights), attrs, static_cast<_Float16*>(zbuf));
   else
     hipLaunchKernelGGL(decoder_forward_kernel<false>, dim3(grid), dim3(FWD_THREADS), lds, static_cast<hipStream_t>(stream),
-                       feat, pos, N, static_cast<const unsigned char*>(packed_weights), attrs, (__bf16*)nullptr);
+                       feat, pos, N, static_cast<const unsigned char*>(packed_weights), attrs, (_Float16*)nullptr);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }
@@ -495,7 +497,7 @@ extern "C" int ggd_decoder_backward(ggd_ctx* ctx, void* stream, int32_t N, const
   int grid = (N + MLP_WAVES * SLAB - 1) / (MLP_WAVES * SLAB);
   if (grid > 256) grid = 256;
   hipLaunchKernelGGL(decoder_backward_kernel, dim3(grid), dim3(MLP_THREADS), HEADT_BYTES, static_cast<hipStream_t>(stream),
-                     N, 0, N, static_cast<const unsigned char*>(packed_t), attrs, dattrs, static_cast<const __bf16*>(zbuf),
+                     N, 0, N, static_cast<const unsigned char*>(packed_t), attrs, dattrs, static_cast<const _Float16*>(zbuf),
                      static_cast<__bf16*>(dzbuf), dout, dfeat, dinfo);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
@@ -565,7 +567,7 @@ extern "C" int ggd_decoder_backward_wgrad(ggd_ctx* ctx, void* stream, int32_t N,
     int grid = (n + MLP_WAVES * SLAB - 1) / (MLP_WAVES * SLAB);
     if (grid > 256) grid = 256;
     hipLaunchKernelGGL(decoder_backward_kernel, dim3(grid), dim3(MLP_THREADS), HEADT_BYTES, s, N, first, last,
-                       static_cast<const unsigned char*>(packed_t), attrs, dattrs, static_cast<const __bf16*>(zbuf),
+                       static_cast<const unsigned char*>(packed_t), attrs, dattrs, static_cast<const _Float16*>(zbuf),
                        static_cast<__bf16*>(dzbuf), dout, dfeat, dinfo);
     int chunks = (n + 4 * WG_K - 1) / (4 * WG_K);
     if (chunks > 128) chunks = 128;

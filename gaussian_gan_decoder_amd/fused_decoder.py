@@ -65,7 +65,7 @@ def _swizzle_rows(wp: torch.Tensor) -> torch.Tensor:
 
 def pack_weights(decoder: SequentialDecoderReverse) -> torch.Tensor:
     """-> uint8 tensor of ggd_decoder_packed_bytes(): per head [W1 128x64 | W2 128x128 | W3 128x128 | W4 16x128] f16 (clamped
-    to +-65504, slots swizzled), then b1 b2 b3 [128] and b4 [16] fp32."""
+    to +-65504, slots swizzled), then b1 b2 b3 [128] and b4 [16] fp32; W1 .. W3 and b1 .. b3 halved."""
     _check_decoder(decoder)
     dev = next(decoder.parameters()).device
     chunks = []
@@ -81,11 +81,13 @@ def pack_weights(decoder: SequentialDecoderReverse) -> torch.Tensor:
         b4 = torch.zeros(16, device=dev)
         b4[:l4.out_features] = l4.bias.detach().float()
         rows = []
-        for w, row in ((w1, ROW1), (l2.weight.detach().float(), ROW2), (l3.weight.detach().float(), ROW2), (w4, ROW2)):
+        # the hidden layers are halved (exact): the forward's accumulators hold z / 2, the form its f16 GELU starts from
+        for w, row in ((0.5 * w1, ROW1), (0.5 * l2.weight.detach().float(), ROW2), (0.5 * l3.weight.detach().float(), ROW2),
+                       (w4, ROW2)):
             assert row == w.shape[1]
             wp = _swizzle_rows(_permute_blocks(w))
             rows.append(wp.clamp(-65504.0, 65504.0).to(torch.float16).contiguous().view(torch.uint8).reshape(-1))
-        biases = torch.cat([l1.bias.detach().float(), l2.bias.detach().float(), l3.bias.detach().float(), b4])
+        biases = torch.cat([0.5 * l1.bias.detach().float(), 0.5 * l2.bias.detach().float(), 0.5 * l3.bias.detach().float(), b4])
         chunks += rows + [biases.contiguous().view(torch.uint8).reshape(-1)]
     packed = torch.cat(chunks).contiguous()
     expect = _capi.load().ggd_decoder_packed_bytes()
@@ -202,7 +204,7 @@ class FusedDecoderFn(torch.autograd.Function):
         n = pos.shape[0]
         cx = _capi.context_for(dev)
         attrs = torch.empty((n, 16), dtype=torch.float32, device=dev)
-        # 16-point blocks (ggd_decoder_zbuf_bytes); bf16 kernels: bf16 values, reference precision: fp16 values (opaque here)
+        # 16-point blocks (ggd_decoder_zbuf_bytes); f16 values in both tiers (opaque here)
         zbuf = torch.empty((5, 3, (n + 15) // 16 * 16, HID), dtype=torch.bfloat16, device=dev)
         fwd = cx.lib.ggd_decoder_forward_hl if hl else cx.lib.ggd_decoder_forward_train
         with torch.cuda.device(dev):
