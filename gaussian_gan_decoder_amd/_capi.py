@@ -43,7 +43,7 @@ class ImgView(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("ranges", "final_T", "n_contrib", "total")]
 
 
-OPT_EXP_MODE, OPT_BLEND_CULL, OPT_BINNING, OPT_BLEND_SPLIT = 0, 1, 2, 3
+OPT_EXP_MODE, OPT_BLEND_CULL, OPT_BINNING, OPT_BLEND_SPLIT, OPT_FOLD = 0, 1, 2, 3, 4
 SPLAT_BYTES = 48
 SPLAT_FIELDS = ("x", "y", "hA", "nB", "hC", "thr", "opacity", "r", "g", "b", "ex", "ey")
 

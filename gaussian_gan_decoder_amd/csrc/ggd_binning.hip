@@ -234,11 +234,27 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
     uint32_t* __restrict__ vals_out, int64_t n_host, int shift, const uint32_t* __restrict__ ghist /*[256] of this pass*/,
     uint32_t* status /*[ntiles + groups][256]*/, int ntiles, int gshift, uint32_t* ticket,
     const uint32_t* __restrict__ n_dev = nullptr, int piggy_role = 0, ggd_scan_piggy pg = ggd_scan_piggy{},
-    uint32_t* __restrict__ flat_flag = nullptr) {
+    uint32_t* __restrict__ flat_flag = nullptr, int hist_reps = 1) {
   __shared__ uint32_t s_cnt[4][RS_BINS];   // per-wave running digit counts -> per-wave scatter bases
   if ((int)blockIdx.x >= ntiles) {   // appended workgroups: steps 2 / 3 of the offsets scan (see ggd_scan_piggy)
-    if (piggy_role == 2) scan_blocksums_block(pg.block_sums, pg.nb, pg.d_total, pg.h_total, &s_cnt[0][0], pg.h_tagged, pg.tag);
-    else scan_apply_block<false>(pg.in, pg.out, pg.n, pg.block_sums, (int)blockIdx.x - ntiles, &s_cnt[0][0]);
+    if (piggy_role == 2 && pg.wg_info) {
+      scan_info_block(pg.wg_info, pg.n_info, pg.block_sums, pg.n_valid, pg.d_total, pg.h_total, &s_cnt[0][0], pg.h_tagged, pg.tag);
+      if (pg.fold_hist) {   // passes 1 .. 3 then read ONE histogram (pass 0's tiles, running beside us, read their own 256 bins
+                            // of every replica: reading all replicas cost each pass ~2 us)
+        uint32_t acc[3] = {0u, 0u, 0u};
+#pragma unroll 8
+        for (int r = 1; r < GGD_FOLD_REPS; ++r) {
+#pragma unroll
+          for (int p = 1; p < 4; ++p) acc[p - 1] += pg.fold_hist[r * GGD_FOLD_REP_STRIDE + p * RS_BINS + threadIdx.x];
+        }
+#pragma unroll
+        for (int p = 1; p < 4; ++p) pg.fold_hist[p * RS_BINS + threadIdx.x] += acc[p - 1];
+      }
+    }
+    else if (piggy_role == 2)
+      scan_blocksums_block(pg.block_sums, pg.nb, pg.d_total, pg.h_total, &s_cnt[0][0], pg.h_tagged, pg.tag);
+    else
+      scan_apply_block<false>(pg.in, pg.out, pg.n, pg.block_sums, (int)blockIdx.x - ntiles, &s_cnt[0][0], pg.sum_stride);
     return;
   }
   __shared__ uint32_t s_scan[4];
@@ -257,7 +273,15 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
   const bool use_ticket = ntiles > RS_RESIDENT;
   if (use_ticket && threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
   const uint32_t n_dev_v = (COMPACT && !IOTA) ? *n_dev : 0u;
-  const uint32_t my_bin = ghist[threadIdx.x];
+  uint32_t my_bin = ghist[threadIdx.x];
+  if (hist_reps > 1) {   // folded front end: GGD_FOLD_REPS replicas, all requested at once (a loop on the runtime count made
+                         // every replica its own round trip: + 7 us per pass)
+    uint32_t rep[GGD_FOLD_REPS - 1];
+#pragma unroll
+    for (int r = 1; r < GGD_FOLD_REPS; ++r) rep[r - 1] = ghist[r * GGD_FOLD_REP_STRIDE + threadIdx.x];
+#pragma unroll
+    for (int r = 1; r < GGD_FOLD_REPS; ++r) my_bin += rep[r - 1];
+  }
   for (int b = threadIdx.x; b < 4 * RS_BINS; b += RS_THREADS) (&s_cnt[0][0])[b] = 0;
   if (threadIdx.x == 0) s_flat = 0u;
   uint32_t tile = blockIdx.x;
@@ -500,33 +524,51 @@ const uint32_t* ggd_sort32_flat_ptr(const void* ctl) {
 
 size_t ggd_sort_ctrl_words() { return sort_ctrl_bytes() / sizeof(uint32_t); }
 
+const uint32_t* ggd_fold_nvalid_ptr(const uint32_t* fold_ctl) { return fold_ctl + GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE + RS_MAX_PASSES; }
+const uint32_t* ggd_fold_flat_ptr(const uint32_t* fold_ctl) { return fold_ctl + GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE + RS_MAX_PASSES + 1; }
+size_t ggd_fold_ctl_words(int64_t P) {
+  const int64_t ntiles = (P + RS32_TILE - 1) / RS32_TILE;
+  return (size_t)GGD_FOLD_HEAD + (size_t)4 * (size_t)rs_status_words(ntiles > 0 ? ntiles : 1);
+}
+
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
-                           uint32_t* clean_ctl, const ggd_scan_piggy* piggy, bool flag_flat_last, bool apply_here) {
+                           uint32_t* clean_ctl, const ggd_scan_piggy* piggy, bool flag_flat_last, bool apply_here,
+                           const ggd_fold* fold) {
   if (n <= 0) return GGD_OK;
   const int passes = sort_passes(nbits);
   if (passes > RS_MAX_PASSES || (passes & 1)) return ggd_fail(ctx, GGD_E_INVALID, "sort32: need an even pass count");
-  if (tmp_bytes < ggd_sort32_tmp_bytes(n)) return ggd_fail(ctx, GGD_E_INVALID, "sort tmp too small");
+  if (fold && (passes != 4 || !piggy || !piggy->wg_info)) return ggd_fail(ctx, GGD_E_INVALID, "sort32: folded front end needs 4 passes and the workgroup sums");
+  if (!fold && tmp_bytes < ggd_sort32_tmp_bytes(n)) return ggd_fail(ctx, GGD_E_INVALID, "sort tmp too small");
   const int ntiles = (int)((n + RS32_TILE - 1) / RS32_TILE);
   // control block (histograms, tickets, n_valid): `clean_ctl` = a block an earlier kernel of this frame has already
   // cleared (then the status words are cleared by the histogram kernel and the sort needs no memset launch), else the
-  // head of tmp
-  uint32_t* ghist = clean_ctl ? clean_ctl : static_cast<uint32_t*>(tmp);
-  uint32_t* tickets = ghist + RS_HWORDS;
-  uint32_t* status = reinterpret_cast<uint32_t*>(static_cast<char*>(tmp) + sort_ctrl_bytes());
+  // head of tmp.  fold: a whole block (status words included) the previous frame's preprocess cleared, histograms (in
+  // GGD_FOLD_REPS replicas) filled by this frame's.
+  uint32_t* ghist = fold ? fold->ctl : (clean_ctl ? clean_ctl : static_cast<uint32_t*>(tmp));
+  uint32_t* tickets = ghist + (fold ? GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE : RS_HWORDS);
+  uint32_t* status = fold ? fold->ctl + GGD_FOLD_HEAD : reinterpret_cast<uint32_t*>(static_cast<char*>(tmp) + sort_ctrl_bytes());
+  const int reps = fold ? GGD_FOLD_REPS : 1;
   const size_t pass_words = (size_t)rs_status_words(ntiles);
   const int gshift = rs_gshift(ntiles);
   const size_t status_bytes = (size_t)passes * pass_words * sizeof(uint32_t);
-  if (!clean_ctl) GGD_HIP(hipMemsetAsync(tmp, 0, sort_ctrl_bytes() + status_bytes, s));
+  if (!clean_ctl && !fold) GGD_HIP(hipMemsetAsync(tmp, 0, sort_ctrl_bytes() + status_bytes, s));
   // keys equal to 0xFFFFFFFF (culled Gaussians) are dropped by pass 0; n_valid (device) = number of kept keys, the
   // element count of every later pass and of the binning that consumes the order (word RS_MAX_PASSES of the tickets)
   uint32_t* n_valid = tickets + RS_MAX_PASSES;
   // the offsets scan rides on the first three launches as appended workgroups (reduce | block sums | apply)
-  const ggd_scan_piggy pg = piggy ? *piggy : ggd_scan_piggy{};
+  ggd_scan_piggy pg = piggy ? *piggy : ggd_scan_piggy{};
   const int pnb = piggy ? pg.nb : 0;
-  hipLaunchKernelGGL((sort_global_hist_kernel<uint32_t, RS32_ITEMS, true>), dim3(ntiles + pnb), dim3(RS_THREADS), 0, s,
-                     keys_src, n, passes, ghist, n_valid, clean_ctl ? status : nullptr,
-                     clean_ctl ? status_bytes / sizeof(uint32_t) : (size_t)0, ntiles, pg);
+  if (fold) { pg.n_valid = n_valid; pg.fold_hist = ghist; }   // (pass 0 does not read n_valid: its appended workgroup writes it
+                                                              // -- and sums the replicas -- for the later passes)
+  if (!fold) {
+    // (tile size of this launch, measured at 1 M keys: 4 / 16 / 32 / 64 keys per thread = 977 / 245 / 123 / 62 workgroups flushing
+    // into the same 1024 words: 50.4 / 19.2 / 19.3 / 29.1 us -- same-address atomics retire at ~43 ns each)
+    const int htiles = ntiles;
+    hipLaunchKernelGGL((sort_global_hist_kernel<uint32_t, RS32_ITEMS, true>), dim3(htiles + pnb), dim3(RS_THREADS), 0, s,
+                       keys_src, n, passes, ghist, n_valid, clean_ctl ? status : nullptr,
+                       clean_ctl ? status_bytes / sizeof(uint32_t) : (size_t)0, htiles, pg);
+  }
   // every pass copies its pairs out of LDS in digit order (STAGE; measured, sort stage with / without: 1 M Gaussians 69.9 /
   // 71.1 us, 5 M 201 / 235, 5 M shell 252 / 342, 10 M 340 / 390)
   // pass 0: keys_src (read-only, caller's buffer) -> B with identity values; then B -> A -> B -> A ...
@@ -538,12 +580,12 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
     if (p == 0)
       hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, true, RS32_ITEMS, true, true>), dim3(ntiles + (pnb ? 1 : 0)),
                          dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 0, ghist, status, ntiles, gshift, tickets, n_valid,
-                         2, pg);
+                         2, pg, (uint32_t*)nullptr, reps);
     if (p != 0)
       hipLaunchKernelGGL((sort_onesweep_kernel<uint32_t, false, RS32_ITEMS, true, true>), dim3(ntiles + ((p == 1 && apply_here) ? pnb : 0)),
                          dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n, 8 * p, ghist + p * RS_BINS,
                          status + (size_t)p * pass_words, ntiles, gshift, tickets + p, n_valid, 3, pg,
-                         (flag_flat_last && p == passes - 1) ? tickets + RS_MAX_PASSES + 1 : nullptr);
+                         (flag_flat_last && p == passes - 1) ? tickets + RS_MAX_PASSES + 1 : nullptr, 1);
     kin = kout; vin = vout;
   }
   GGD_HIP(hipGetLastError());

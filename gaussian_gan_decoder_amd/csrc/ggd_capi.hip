@@ -150,6 +150,7 @@ extern "C" void ggd_destroy(ggd_ctx* ctx) {
   if (ctx->d_words) (void)hipFree(ctx->d_words);
   if (ctx->h_words) (void)hipHostFree(ctx->h_words);
   if (ctx->sortctl) (void)hipFree(ctx->sortctl);
+  for (int b = 0; b < 2; ++b) if (ctx->foldctl[b]) (void)hipFree(ctx->foldctl[b]);
   if (ctx->gelu_tables) (void)hipFree(ctx->gelu_tables);
   if (ctx->scan_sums) (void)hipFree(ctx->scan_sums);
   if (ctx->stats_buf) (void)hipFree(ctx->stats_buf);
@@ -164,7 +165,7 @@ extern "C" const char* ggd_last_error(ggd_ctx* ctx) { return ctx ? ctx->err.c_st
 
 extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
   if (!ctx) return GGD_E_INVALID;
-  static const int kMax[GGD_OPT_COUNT] = {2, 1, 3, 4};
+  static const int kMax[GGD_OPT_COUNT] = {2, 1, 3, 4, 1};
   if (option < 0 || option >= GGD_OPT_COUNT || value < 0 || value > kMax[option])
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_set_option: unknown option or value");
   ctx->opt[option] = value;
@@ -284,19 +285,58 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
   rc = ggd_reserve_scratch(ctx, scan_tmp, s);
   if (rc != GGD_OK) return rc;
   if (prm->prefiltered) GGD_HIP(hipMemsetAsync(ctx->d_words + 1, 0, sizeof(uint32_t), s));
+  // single-call forward on a tile-binning path: the scan (offsets + num_rendered) rides on the depth sort's launches, and the
+  // sort's histograms + the scan's first step are produced by the preprocess kernel itself (ggd_fold)
+  const bool ride = defer_scan && ctx->h_words_dev;
+  ggd_fold fold;
+  ctx->fold_active = false;
+  if (ride && ctx->opt[GGD_OPT_FOLD] != 0) {
+    const int nwg = (prm->P + 255) / 256;
+    if (ctx->scan_sums_cap < 3 * nwg + 64) {   // [exclusive prefixes: nwg words | {sum, kept}: nwg uint2]
+      if (ctx->scan_sums) (void)hipFree(ctx->scan_sums);
+      ctx->scan_sums = nullptr; ctx->scan_sums_cap = 0;
+      const int cap = 3 * (nwg + nwg / 2) + 64;
+      GGD_HIP(hipMalloc((void**)&ctx->scan_sums, (size_t)cap * sizeof(uint32_t)));
+      ctx->scan_sums_cap = cap;
+    }
+    const size_t need = ggd_fold_ctl_words(prm->P);
+    if (ctx->foldctl_cap < need) {   // (grow-only; both blocks start clean)
+      GGD_HIP(hipStreamSynchronize(s));
+      for (int b = 0; b < 2; ++b) { if (ctx->foldctl[b]) (void)hipFree(ctx->foldctl[b]); ctx->foldctl[b] = nullptr; }
+      ctx->foldctl_cap = 0;
+      const size_t cap = need + need / 2;
+      for (int b = 0; b < 2; ++b) {
+        GGD_HIP(hipMalloc((void**)&ctx->foldctl[b], cap * sizeof(uint32_t)));
+        GGD_HIP(hipMemsetAsync(ctx->foldctl[b], 0, cap * sizeof(uint32_t), s));
+        ctx->foldctl_dirty[b] = 0;
+      }
+      ctx->foldctl_cap = cap;
+      ctx->fold_cur = 0;
+    }
+    const int cur = ctx->fold_cur, oth = cur ^ 1;
+    fold.ctl = ctx->foldctl[cur];
+    fold.clear = ctx->foldctl[oth];
+    fold.clear_words = (uint32_t)ctx->foldctl_dirty[oth];
+    fold.wg_info = reinterpret_cast<uint2*>(ctx->scan_sums + (((size_t)nwg + 1) & ~(size_t)1));
+    ctx->foldctl_dirty[oth] = 0;       // (clean once this launch has run)
+    ctx->foldctl_dirty[cur] = need;    // what this frame may write
+    ctx->fold_cur = oth;
+    ctx->fold_active = true;
+  }
   {
     StageTimer t(ctx, ST_PREPROCESS, s);
+    const bool old_ctl = !ctx->fold_active && ctx->sortctl;
     rc = ggd_launch_preprocess(ctx, s, *prm, means3D, shs, colors_precomp, opacities, scales, rotations,
                                cov3D_precomp, splat, tiles, shs ? clamped : nullptr, radii, depth_keys, rect,
-                               ctx->d_words + 1, ctx->sortctl, ctx->sortctl ? (int)ggd_sort_ctrl_words() : 0);
-    if (rc != GGD_OK) return rc;
-    ctx->sortctl_clean = ctx->sortctl != nullptr;
+                               ctx->d_words + 1, old_ctl ? ctx->sortctl : nullptr, old_ctl ? (int)ggd_sort_ctrl_words() : 0,
+                               ctx->fold_active ? &fold : nullptr);
+    if (rc != GGD_OK) { ctx->fold_active = false; return rc; }
+    ctx->sortctl_clean = old_ctl;
   }
   ctx->scan_deferred = false;
-  if (defer_scan && ctx->h_words_dev) {
-    // single-call forward on a tile-binning path: the scan (offsets + num_rendered) rides on the depth sort's launches
+  if (ride) {
     const int nb = ggd_scan_blocks(prm->P);
-    if (ctx->scan_sums_cap < nb) {
+    if (!ctx->fold_active && ctx->scan_sums_cap < nb) {
       if (ctx->scan_sums) (void)hipFree(ctx->scan_sums);
       ctx->scan_sums = nullptr; ctx->scan_sums_cap = 0;
       GGD_HIP(hipMalloc((void**)&ctx->scan_sums, (size_t)(nb + nb / 2 + 64) * sizeof(uint32_t)));
@@ -433,12 +473,15 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
     uint32_t* clean_ctl = nullptr;
     ggd_scan_piggy pg;          // a scan that rides on this call's launches (see geometry_enqueue)
     bool riding = false;
+    const uint32_t *n_vis_ptr = nullptr, *flat_ptr = nullptr;   // device words: kept keys, "last pass was flat"
     {
       StageTimer t(ctx, ST_SORT, s);
       // the control block this frame's scan cleared, if nobody has used it since (a second render of the same geometry
       // falls back to the memset)
       clean_ctl = ctx->sortctl_clean ? ctx->sortctl : nullptr;
       ctx->sortctl_clean = false;
+      ggd_fold fold;
+      const bool folded = ctx->scan_deferred && ctx->fold_active;   // this call's preprocess filled the histograms
       if (ctx->scan_deferred) {   // this call's geometry half left the scan to us
         uint32_t* tiles_w = reinterpret_cast<uint32_t*>(const_cast<char*>(gb) + gv.tiles_touched);
         pg.in = tiles_w; pg.out = reinterpret_cast<uint32_t*>(const_cast<char*>(gb) + gv.point_offsets);
@@ -446,21 +489,32 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
         pg.d_total = ctx->d_words; pg.h_total = ctx->h_words_dev;
         pg.h_tagged = reinterpret_cast<unsigned long long*>(ctx->h_words_dev + 2);
         pg.tag = ++ctx->r_tag;
+        if (folded) {
+          const int nwg = (prm->P + 255) / 256;
+          fold.ctl = ctx->foldctl[ctx->fold_cur ^ 1];   // (fold_cur already points at the next frame's block)
+          pg.wg_info = reinterpret_cast<const uint2*>(ctx->scan_sums + (((size_t)nwg + 1) & ~(size_t)1));
+          pg.n_info = nwg;
+          pg.sum_stride = 8;                            // 2048-element scan blocks over 256-point workgroup prefixes
+        }
       }
+      ctx->fold_active = false;
       riding = ctx->scan_deferred;
-      rc = ggd_launch_sort32_iota(ctx, s, depth_keys, ka, va, kb, vb, prm->P, 32, tmp, sort_tmp, clean_ctl,
-                                  riding ? &pg : nullptr, rowbin, !rowbin);
+      rc = ggd_launch_sort32_iota(ctx, s, depth_keys, ka, va, kb, vb, prm->P, 32, tmp, sort_tmp, folded ? nullptr : clean_ctl,
+                                  riding ? &pg : nullptr, rowbin, !rowbin, folded ? &fold : nullptr);
       ctx->r_pending = riding && rc == GGD_OK;
       ctx->scan_deferred = false;
       if (rc != GGD_OK) return rc;
+      if (folded) { n_vis_ptr = ggd_fold_nvalid_ptr(fold.ctl); flat_ptr = ggd_fold_flat_ptr(fold.ctl); }
+      else {
+        const void* ctl = clean_ctl ? static_cast<const void*>(clean_ctl) : tmp;
+        n_vis_ptr = ggd_sort32_nvalid_ptr(ctl); flat_ptr = ggd_sort32_flat_ptr(ctl);
+      }
     }
     {
       StageTimer t(ctx, ST_DUPLICATE, s);
       // the depth sort dropped the culled Gaussians (key 0xFFFFFFFF) and left the number of kept ones on the device
-      const uint32_t* n_vis = ggd_sort32_nvalid_ptr(clean_ctl ? static_cast<const void*>(clean_ctl) : tmp);
-      const void* ctl = clean_ctl ? static_cast<const void*>(clean_ctl) : tmp;
-      rc = ggd_launch_rowbin(ctx, s, *prm, rect, va, n_vis, list, ranges, capacity, bin_tmp_ptr, bin_tmp, vb,
-                             ggd_sort32_flat_ptr(ctl), riding ? &pg : nullptr);
+      rc = ggd_launch_rowbin(ctx, s, *prm, rect, va, n_vis_ptr, list, ranges, capacity, bin_tmp_ptr, bin_tmp, vb,
+                             flat_ptr, riding ? &pg : nullptr);
       if (rc != GGD_OK) return rc;
     }
   } else {

@@ -39,6 +39,12 @@ struct ggd_ctx {
   bool sortctl_clean = false;       // cleared by this frame's preprocess and not yet consumed by a sort
   uint32_t* scan_sums = nullptr;    // block sums of a scan that rides on the depth sort (own allocation, grow-only)
   int scan_sums_cap = 0;
+  // depth-sort front end folded into the preprocess kernel (ggd_fold below): two control blocks used alternately
+  uint32_t* foldctl[2] = {nullptr, nullptr};
+  size_t foldctl_cap = 0;           // words per block
+  size_t foldctl_dirty[2] = {0, 0}; // words of each block its last user may have written (what the next clear must cover)
+  int fold_cur = 0;                 // block the next folding preprocess accumulates into (cleared by the previous one)
+  bool fold_active = false;         // this call's preprocess left histograms + workgroup sums for the sort of the same call
   bool scan_deferred = false;       // geometry_enqueue left the scan to the sort launches of the same call
   void* gelu_tables = nullptr;      // GELU / GELU' interpolation tables of the reference-precision decoder kernels (built on first use)
   uint32_t r_tag = 0;               // sequence number of the single-call forward whose num_rendered the host is waiting for
@@ -46,7 +52,7 @@ struct ggd_ctx {
   void* dbg_keys = nullptr;     // debug copy of the unsorted list
   void* dbg_vals = nullptr;
   size_t dbg_cap = 0;
-  int opt[GGD_OPT_COUNT] = {2, 1, 1, 1};  // exp: compensated 2^x (1-ulp class like ocml expf, ~8 % faster blend)
+  int opt[GGD_OPT_COUNT] = {2, 1, 1, 1, 1};  // exp: compensated 2^x (1-ulp class like ocml expf, ~8 % faster blend)
   unsigned long long* blend_stats = nullptr;  // debug: device counters filled by the forward blend when non-null
   unsigned long long* stats_buf = nullptr;    // its storage: [0..4] counters, [GGD_STATS_MODE] 1 = per-wave timeline, slots from GGD_STATS_HEAD
   bool profiling = false;
@@ -70,7 +76,32 @@ struct ggd_scan_piggy {
   unsigned long long* h_tagged = nullptr;   // device view of a pinned 64-bit word that receives (tag << 32 | total): the host
   uint32_t tag = 0;                         // polls it instead of waiting on an event (an event record between two kernels
                                             // costs the GPU a ~6 us bubble)
+  // folded front end (ggd_fold): step 1 was done by the preprocess workgroups (256 points each) -- step 2 scans their sums
+  const uint2* wg_info = nullptr;           // [n_info] {sum of tiles_touched, kept depth keys} per preprocess workgroup
+  int n_info = 0;
+  uint32_t* n_valid = nullptr;              // receives the number of kept keys (sum of wg_info[].y)
+  int sum_stride = 1;                       // block_sums entries per scan block of step 3 (8 with wg_info: 2048 / 256)
+  uint32_t* fold_hist = nullptr;            // the folded front end's histogram replicas: the workgroup that runs step 2 also adds
+                                            // replicas 1 .. REPS-1 of passes 1 .. 3 into replica 0 (only pass 0 reads them all)
 };
+
+// The depth sort's histogram kernel folded into the preprocess kernel (single-call forward on the tile-binning path): every
+// preprocess workgroup adds the digit counts of its kept depth keys to one of GGD_FOLD_REPS replicas of the four 256-bin
+// histograms and stores {sum of tiles_touched, kept keys} of its 256 points -- the histogram launch (19 us at 1 M points:
+// its 245 workgroups flush into 1024 words, and same-address atomics retire at ~43 ns each on this part) and
+// step 1 of the offsets scan disappear.  Control block (words): [REPS * 1024 histograms | 8 tickets | n_valid | flat | pad
+// to 64 | status words of the 4 passes]; two blocks alternate, each cleared by the preprocess of the frame before its use.
+constexpr int GGD_FOLD_REPS = 16;   // (32 / 16 / 8 replicas: 4114 / 4140 / 4150 frames per second at 1 M / 1024^2; 3907 workgroups over 8 would
+                                    // keep one address busy 80 % of the kernel's time, 16 leaves a margin)
+constexpr int GGD_FOLD_REP_STRIDE = 4 * 256;
+constexpr int GGD_FOLD_HEAD = GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE + 64;   // words in front of the status words
+struct ggd_fold {
+  uint32_t* ctl = nullptr;        // this frame's control block (clean)
+  uint32_t* clear = nullptr;      // the other block ...
+  uint32_t clear_words = 0;       // ... and how much of it the preprocess clears for the next frame
+  uint2* wg_info = nullptr;       // [ceil(P / 256)]
+};
+size_t ggd_fold_ctl_words(int64_t P);
 
 int ggd_fail(ggd_ctx* ctx, int code, const std::string& msg);
 int ggd_reserve_scratch(ggd_ctx* ctx, size_t bytes, hipStream_t stream);
@@ -106,7 +137,8 @@ int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, co
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           ggd_splat* splat, uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii,
                           uint32_t* depth_keys, uint2* rect, uint32_t* trap_flag, uint32_t* zero_ptr = nullptr,
-                          int zero_words = 0);   // zero_words words at zero_ptr are cleared by the first workgroups
+                          int zero_words = 0,    // zero_words words at zero_ptr are cleared by the first workgroups
+                          const ggd_fold* fold = nullptr);
 int ggd_launch_mark_visible(ggd_ctx* ctx, hipStream_t s, int P, const float* means3D, const float* view,
                             uint8_t* present);
 // inclusive scan of a uint32 array; total written to *d_total (device)
@@ -134,10 +166,15 @@ int ggd_launch_sort(ggd_ctx* ctx, hipStream_t s, uint64_t* keys_a, uint32_t* val
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
                            uint32_t* clean_ctl = nullptr, const ggd_scan_piggy* piggy = nullptr,
-                           bool flag_flat_last = false, bool apply_here = true);   // apply_here = false: the caller runs the
-                           // scan's last step (offsets) elsewhere -- ggd_launch_rowbin(apply = ...)        // a constant-digit LAST pass copies nothing: it sets the word
-                                                                // ggd_sort32_flat_ptr(ctl) and the result stays in (keys_b, vals_b)
+                           bool flag_flat_last = false, bool apply_here = true, const ggd_fold* fold = nullptr);
+// flag_flat_last: a constant-digit LAST pass copies nothing -- it sets the word ggd_sort32_flat_ptr(ctl) and the result
+//                 stays in (keys_b, vals_b)
+// apply_here = false: the caller runs the riding scan's last step (offsets) elsewhere -- ggd_launch_rowbin(apply = ...)
+// fold: histograms, kept-key count and the scan's step 1 come from the preprocess kernel (piggy must carry wg_info); no
+//       histogram launch
 const uint32_t* ggd_sort32_flat_ptr(const void* ctl);
+const uint32_t* ggd_fold_nvalid_ptr(const uint32_t* fold_ctl);   // the same two words of a folded front end's control block
+const uint32_t* ggd_fold_flat_ptr(const uint32_t* fold_ctl);
 // Tile binning (GGD_OPT_BINNING = 1): sorted Gaussian order -> per-tile lists + ranges.
 bool ggd_rowbin_supported(int W, int H);
 size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity, int W, int H);

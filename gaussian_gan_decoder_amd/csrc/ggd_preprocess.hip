@@ -15,7 +15,11 @@ using namespace ggdm;
 // SHVEC (more than the band-0 coefficient per channel, rows a multiple of 16 bytes: M = 4, 8, 12, 16): a visible Gaussian's
 // 3 M coefficients are fetched as 3 M / 4 dwordx4 loads into registers instead of 3 M lone words -- each such load
 // instruction touches 64 different rows whatever its width (1 M Gaussians, M = 16: preprocess 76 -> see DESIGN.md).
-template <bool SHVEC>
+// FOLD (ggd_fold, single-call forward on the tile-binning path): the workgroup also (a) clears its share of the OTHER
+// control block for the next frame, (b) adds the four digit counts of its kept depth keys to replica blockIdx % REPS of the
+// depth sort's histograms (LDS histogram first; bins that stayed empty cost nothing), (c) stores {sum of tiles_touched, kept
+// keys} of its 256 points for the offsets scan -- the sort's histogram launch and the scan's first step disappear.
+template <bool SHVEC, bool FOLD>
 __global__ __launch_bounds__(256) void preprocess_kernel(
     int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered, int raw,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos_p,
@@ -23,15 +27,28 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, ggd_splat* __restrict__ splat, uint32_t* __restrict__ tiles_touched,
     uint8_t* __restrict__ clamped, int32_t* __restrict__ radii, uint32_t* __restrict__ depth_keys,
-    uint2* __restrict__ rect, uint32_t* __restrict__ trap_flag, uint32_t* __restrict__ zero_ptr, int zero_words) {
-  // first kernel of a frame: its first workgroups also clear the depth sort's control block (no memset launch there)
-  {
+    uint2* __restrict__ rect, uint32_t* __restrict__ trap_flag, uint32_t* __restrict__ zero_ptr, int zero_words,
+    ggd_fold fold) {
+  __shared__ uint32_t s_hist[FOLD ? 4 * 256 : 1];
+  __shared__ uint32_t s_red[FOLD ? 8 : 1];
+  if constexpr (FOLD) {
+    for (uint32_t z = blockIdx.x * 256 + threadIdx.x; z < fold.clear_words; z += gridDim.x * 256) fold.clear[z] = 0u;
+    for (int b = threadIdx.x; b < 4 * 256; b += 256) s_hist[b] = 0u;
+    __syncthreads();
+  } else {
+    // first kernel of a frame: its first workgroups also clear the depth sort's control block (no memset launch there)
     const int zb = min(8, (int)gridDim.x);
     if ((int)blockIdx.x < zb)
       for (int z = blockIdx.x * 256 + threadIdx.x; z < zero_words; z += zb * 256) zero_ptr[z] = 0u;
   }
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= P) return;
+  const bool in_range = i < P;
+  if (!FOLD && !in_range) return;
+  int irad = 0;
+  uint32_t ntiles = 0;
+  bool visible = false;
+  float depth = 0.0f;
+  if (in_range) {
   const Mat16 V = load_mat(view);
   const Mat16 PV = load_mat(proj);
 
@@ -40,10 +57,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   t[0] = V.m[0] * p[0] + V.m[4] * p[1] + V.m[8] * p[2] + V.m[12];
   t[1] = V.m[1] * p[0] + V.m[5] * p[1] + V.m[9] * p[2] + V.m[13];
   t[2] = V.m[2] * p[0] + V.m[6] * p[1] + V.m[10] * p[2] + V.m[14];
+  depth = t[2];
 
-  int irad = 0;
-  uint32_t ntiles = 0;
-  bool visible = false;
   ggd_splat out;
   uint32_t clamp_bits = 0;
   uint2 rect_out = make_uint2(0u, 0u);
@@ -163,6 +178,43 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float4* src = reinterpret_cast<const float4*>(&out);
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
   }
+  }  // in_range
+  if constexpr (FOLD) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t key = __float_as_uint(depth);
+    const uint64_t act = __ballot(visible);
+    if (act != 0ull) {
+      // (as sort_global_hist_kernel: the two high bytes -- sign / exponent / leading mantissa bits of a depth -- are usually
+      // shared by the whole wave: one lane adds the count instead of 64 conflicting LDS atomics)
+      const int leader = __builtin_ctzll(act);
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const uint32_t d = (key >> (8 * pass)) & 0xffu;
+        if (pass < 2) {
+          if (visible) atomicAdd(&s_hist[pass * 256 + d], 1u);
+          continue;
+        }
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
+        if (__ballot(visible && d != d0) == 0ull) {
+          if (lane == leader) atomicAdd(&s_hist[pass * 256 + d0], (uint32_t)__popcll(act));
+        } else if (visible) {
+          atomicAdd(&s_hist[pass * 256 + d], 1u);
+        }
+      }
+    }
+    uint32_t tsum = ntiles;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) tsum += __shfl_xor(tsum, sh, 64);
+    if (lane == 0) { s_red[wv] = tsum; s_red[4 + wv] = (uint32_t)__popcll(act); }
+    __syncthreads();
+    uint32_t* hist = fold.ctl + (blockIdx.x % GGD_FOLD_REPS) * GGD_FOLD_REP_STRIDE;
+    for (int b = threadIdx.x; b < 4 * 256; b += 256) {
+      const uint32_t c = s_hist[b];
+      if (c) atomicAdd(&hist[b], c);
+    }
+    if (threadIdx.x == 0)
+      fold.wg_info[blockIdx.x] = make_uint2(s_red[0] + s_red[1] + s_red[2] + s_red[3], s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+  }
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ means3D,
@@ -181,22 +233,21 @@ int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, co
                           const float* shs, const float* colors_precomp, const float* opacities,
                           const float* scales, const float* rotations, const float* cov3D_precomp,
                           ggd_splat* splat, uint32_t* tiles_touched, uint8_t* clamped, int32_t* radii,
-                          uint32_t* depth_keys, uint2* rect, uint32_t* trap_flag, uint32_t* zero_ptr, int zero_words) {
+                          uint32_t* depth_keys, uint2* rect, uint32_t* trap_flag, uint32_t* zero_ptr, int zero_words,
+                          const ggd_fold* fold) {
   if (prm.P == 0) return GGD_OK;
   const int grid = (prm.P + 255) / 256;
   const bool shvec = !colors_precomp && prm.M > 1 && prm.M <= 16 && ((3 * prm.M) & 3) == 0;
-  if (shvec)
-    hipLaunchKernelGGL(preprocess_kernel<true>, dim3(grid), dim3(256), 0, s, prm.P, prm.M, prm.sh_degree, prm.width,
-                       prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.raw_attributes, prm.viewmatrix,
-                       prm.projmatrix, prm.campos, means3D, shs, colors_precomp, opacities, scales, rotations,
-                       cov3D_precomp, splat, tiles_touched, clamped, radii, depth_keys, rect, trap_flag, zero_ptr,
-                       zero_ptr ? zero_words : 0);
-  else
-    hipLaunchKernelGGL(preprocess_kernel<false>, dim3(grid), dim3(256), 0, s, prm.P, prm.M, prm.sh_degree, prm.width,
-                       prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.raw_attributes, prm.viewmatrix,
-                       prm.projmatrix, prm.campos, means3D, shs, colors_precomp, opacities, scales, rotations,
-                       cov3D_precomp, splat, tiles_touched, clamped, radii, depth_keys, rect, trap_flag, zero_ptr,
-                       zero_ptr ? zero_words : 0);
+  const ggd_fold f = fold ? *fold : ggd_fold{};
+#define GGD_PREPROCESS(SHV, FLD)                                                                                            \
+  hipLaunchKernelGGL((preprocess_kernel<SHV, FLD>), dim3(grid), dim3(256), 0, s, prm.P, prm.M, prm.sh_degree, prm.width,     \
+                     prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.raw_attributes,          \
+                     prm.viewmatrix, prm.projmatrix, prm.campos, means3D, shs, colors_precomp, opacities, scales, rotations, \
+                     cov3D_precomp, splat, tiles_touched, clamped, radii, depth_keys, rect, trap_flag, zero_ptr,             \
+                     zero_ptr ? zero_words : 0, f)
+  if (fold) { if (shvec) GGD_PREPROCESS(true, true); else GGD_PREPROCESS(false, true); }
+  else { if (shvec) GGD_PREPROCESS(true, false); else GGD_PREPROCESS(false, false); }
+#undef GGD_PREPROCESS
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }

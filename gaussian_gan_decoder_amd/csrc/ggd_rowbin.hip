@@ -328,7 +328,7 @@ __global__ __launch_bounds__(RB_THREADS) void rb_scatter2_kernel(const uint2* __
   __shared__ uint32_t wcnt[RB_WAVES][64];
   __shared__ uint32_t stage[RB_STAGE];
   if (blockIdx.x >= main_blocks) {   // appended workgroups: last step of the offsets scan (see ggd_scan_piggy)
-    scan_apply_block<false>(pg.in, pg.out, pg.n, pg.block_sums, (int)(blockIdx.x - main_blocks), stage);
+    scan_apply_block<false>(pg.in, pg.out, pg.n, pg.block_sums, (int)(blockIdx.x - main_blocks), stage, pg.sum_stride);
     return;
   }
   int row; uint32_t chunk;

@@ -210,6 +210,9 @@ enum {
                              4 = four independent quarter waves per tile; 1 (default) = auto (4 from 2048 tiles, else 3);
                              0, 2 = aliases of 3 (the one-wave and two-wave forms they selected were removed).  Backward sums
                              differ only in their fp32 summation order. */
+  GGD_OPT_FOLD = 4,       /* single-call forward on the tile-binning path: 1 (default) = the per-Gaussian kernel also builds the
+                             depth sort's digit histograms and the first step of the offsets scan (no histogram launch);
+                             0 = separate histogram launch.  Results are identical. */
   GGD_OPT_COUNT
 };
 int ggd_set_option(ggd_ctx* ctx, int option, int value);

@@ -316,22 +316,58 @@ def test_collisions_and_degenerate_members(native_lib):
         assert np.abs(n["color"].cpu().numpy() - o["color"])[:, same].max() <= RGB_ATOL
 
 
-@pytest.mark.parametrize("P", [1, 63, 2047, 2048, 2049, 4095, 4096, 4097, 8193, 12289])
+@pytest.mark.parametrize("P", [1, 63, 255, 256, 257, 2047, 2048, 2049, 4095, 4096, 4097, 8193, 12289])
 def test_single_call_forward_at_block_boundaries(native_lib, P):
-    """Sizes around the workgroup granularities of the scan (2048), the depth sort (4096) and the binning chunks (1024): the
-    single-call forward (scan steps riding on the sort / binning launches, num_rendered polled from the pinned word) must
-    reproduce the two-call forward and the oracle bit for bit."""
+    """Sizes around the workgroup granularities of the per-Gaussian kernel (256), the scan (2048), the depth sort (4096) and
+    the binning chunks (1024): the single-call forward (scan steps riding on the sort / binning launches, num_rendered polled
+    from the pinned word) must reproduce the two-call forward and the oracle bit for bit -- with the depth sort's histograms
+    and the scan's first step built by the per-Gaussian kernel (GGD_OPT_FOLD = 1, the default: several frames in a row, the
+    two control blocks alternate) and with the separate histogram launch (0)."""
     from gaussian_gan_decoder_amd import _capi
     d = scene_inputs(P=P, size=96, lsm=-4.5, seed=100 + P, width=96, height=80)
     ctx = _capi.context_for(torch.device("cuda:0"))
     ctx.capacity_hint.pop((P, 96, 80), None)
     o = run_oracle(d)
-    first = run_native(d, debug=False)        # no hint yet: two-call form
-    second = run_native(d, debug=False)       # hint: single-call form
-    for n in (first, second):
+    saved = ctx.get_option(_capi.OPT_FOLD)
+    try:
+        first = run_native(d, debug=False)        # no hint yet: two-call form
+        runs = [first]
+        for fold in (1, 1, 1, 0, 1):              # hint: single-call form
+            ctx.set_option(_capi.OPT_FOLD, fold)
+            runs.append(run_native(d, debug=False))
+    finally:
+        ctx.set_option(_capi.OPT_FOLD, saved)
+    for n in runs:
         assert n["num_rendered"] == o["num_rendered"]
         np.testing.assert_array_equal(n["tiles_touched"], o["tiles_touched"])
         np.testing.assert_array_equal(n["point_offsets"], o["point_offsets"])
         np.testing.assert_array_equal(n["point_list"], o["point_list"])
         np.testing.assert_array_equal(n["ranges"], o["ranges"])
-    assert torch.equal(first["color"], second["color"])
+        assert torch.equal(first["color"], n["color"])
+
+
+def test_folded_sort_front_end_across_scenes_of_different_size_and_depth_range(native_lib):
+    """The per-Gaussian kernel of frame k clears the control block frame k + 1 accumulates into: alternate scenes of different
+    P (the block's used extent changes), a scene whose depths span many binades (no constant digit: all four sort passes
+    rank) and one that is culled entirely; every frame must match the oracle's lists."""
+    from gaussian_gan_decoder_amd import _capi
+    ctx = _capi.context_for(torch.device("cuda:0"))
+    scenes = [scene_inputs(P=30011, size=128, lsm=-4.5, seed=7), scene_inputs(P=3001, size=128, lsm=-4.0, seed=8),
+              scene_inputs(P=30011, size=128, lsm=-4.5, seed=9), scene_inputs(P=700, size=128, lsm=-3.5, seed=10)]
+    deep = scene_inputs(P=20000, size=128, lsm=-4.5, seed=11)
+    g = torch.Generator().manual_seed(12)
+    deep["means3D"] = (deep["means3D"] * torch.exp(3.0 * torch.rand(20000, 1, generator=g))).contiguous()   # depths over ~4 binades
+    gone = scene_inputs(P=5000, size=128, lsm=-4.5, seed=13)
+    gone["means3D"] = (gone["means3D"] + 1000.0 * gone["viewmatrix"][:3, 0]).contiguous()                    # far off to the side
+    scenes += [deep, gone, scenes[0]]
+    oracles = [run_oracle(d) for d in scenes]
+    for d in scenes:   # hints for every shape first (two-call form), then three rounds of single-call frames
+        run_native(d, debug=False)
+    assert oracles[-2]["num_rendered"] == 0
+    for _ in range(3):
+        for d, o in zip(scenes, oracles):
+            n = run_native(d, debug=False)
+            assert n["num_rendered"] == o["num_rendered"]
+            np.testing.assert_array_equal(n["point_offsets"], o["point_offsets"])
+            np.testing.assert_array_equal(n["point_list"], o["point_list"])
+            np.testing.assert_array_equal(n["ranges"], o["ranges"])
