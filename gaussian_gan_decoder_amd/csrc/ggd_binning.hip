@@ -146,8 +146,12 @@ constexpr int RS_BATCH = 16;     // status words requested together while summin
 constexpr uint32_t RS_FLAG = 1u << 30, RS_COUNT_MASK = (1u << 30) - 1u;
 // tiles per group of the two-level prefix: the power of two nearest to sqrt(ntiles) from above
 static inline int rs_gshift(int64_t ntiles) { int g = 2; while (((int64_t)1 << (2 * g)) < ntiles) ++g; return g; }
-static inline int64_t rs_status_words(int64_t ntiles) {   // per pass: tile words, then group words
-  return (ntiles + (ntiles >> rs_gshift(ntiles)) + 1) * RS_BINS;
+// per pass: tile words, then group words.  A pass picks its group size from the number of tiles that hold elements (a
+// device-side count in the compacting sort): g <= rs_gshift(ntiles) with up to 2^g groups in use -- more than
+// ntiles >> rs_gshift(ntiles) when the count falls just below a power of four (257 launched tiles, 256 live ones: 16 groups
+// against 9 rows; the overflow landed in the next pass's tile words).  2^rs_gshift + 1 rows cover every choice.
+static inline int64_t rs_status_words(int64_t ntiles) {
+  return (ntiles + ((int64_t)1 << rs_gshift(ntiles)) + 1) * RS_BINS;
 }
 
 __device__ __forceinline__ uint32_t rs_load(uint32_t* p) {
@@ -526,9 +530,13 @@ size_t ggd_sort_ctrl_words() { return sort_ctrl_bytes() / sizeof(uint32_t); }
 
 const uint32_t* ggd_fold_nvalid_ptr(const uint32_t* fold_ctl) { return fold_ctl + GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE + RS_MAX_PASSES; }
 const uint32_t* ggd_fold_flat_ptr(const uint32_t* fold_ctl) { return fold_ctl + GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE + RS_MAX_PASSES + 1; }
-size_t ggd_fold_ctl_words(int64_t P) {
+size_t ggd_fold_l1_offset(int64_t P) {
   const int64_t ntiles = (P + RS32_TILE - 1) / RS32_TILE;
   return (size_t)GGD_FOLD_HEAD + (size_t)4 * (size_t)rs_status_words(ntiles > 0 ? ntiles : 1);
+}
+size_t ggd_fold_ctl_words(int64_t P) {   // + level-1 binning: one 64-word row per 1024-Gaussian chunk and per group of chunks
+  const int64_t chunks = (P + 1023) / 1024;
+  return ggd_fold_l1_offset(P) + (size_t)(chunks + ((int64_t)1 << rs_gshift(chunks > 0 ? chunks : 1)) + 2) * 64;
 }
 
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,

@@ -318,6 +318,7 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
     fold.clear = ctx->foldctl[oth];
     fold.clear_words = (uint32_t)ctx->foldctl_dirty[oth];
     fold.wg_info = reinterpret_cast<uint2*>(ctx->scan_sums + (((size_t)nwg + 1) & ~(size_t)1));
+    fold.rows = ((prm->width + 15) / 16 <= 64 && (prm->height + 15) / 16 <= 64) ? 1 : 0;
     ctx->foldctl_dirty[oth] = 0;       // (clean once this launch has run)
     ctx->foldctl_dirty[cur] = need;    // what this frame may write
     ctx->fold_cur = oth;
@@ -474,6 +475,7 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
     ggd_scan_piggy pg;          // a scan that rides on this call's launches (see geometry_enqueue)
     bool riding = false;
     const uint32_t *n_vis_ptr = nullptr, *flat_ptr = nullptr;   // device words: kept keys, "last pass was flat"
+    uint32_t* folded_l1 = nullptr;                              // the folded front end's control block, if this call has one
     {
       StageTimer t(ctx, ST_SORT, s);
       // the control block this frame's scan cleared, if nobody has used it since (a second render of the same geometry
@@ -504,7 +506,7 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
       ctx->r_pending = riding && rc == GGD_OK;
       ctx->scan_deferred = false;
       if (rc != GGD_OK) return rc;
-      if (folded) { n_vis_ptr = ggd_fold_nvalid_ptr(fold.ctl); flat_ptr = ggd_fold_flat_ptr(fold.ctl); }
+      if (folded) { n_vis_ptr = ggd_fold_nvalid_ptr(fold.ctl); flat_ptr = ggd_fold_flat_ptr(fold.ctl); folded_l1 = fold.ctl; }
       else {
         const void* ctl = clean_ctl ? static_cast<const void*>(clean_ctl) : tmp;
         n_vis_ptr = ggd_sort32_nvalid_ptr(ctl); flat_ptr = ggd_sort32_flat_ptr(ctl);
@@ -513,8 +515,10 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
     {
       StageTimer t(ctx, ST_DUPLICATE, s);
       // the depth sort dropped the culled Gaussians (key 0xFFFFFFFF) and left the number of kept ones on the device
+      const bool l1 = folded_l1 != nullptr && (prm->width + 15) / 16 <= 64 && (prm->height + 15) / 16 <= 64;
       rc = ggd_launch_rowbin(ctx, s, *prm, rect, va, n_vis_ptr, list, ranges, capacity, bin_tmp_ptr, bin_tmp, vb,
-                             flat_ptr, riding ? &pg : nullptr);
+                             flat_ptr, riding ? &pg : nullptr, l1 ? folded_l1 + GGD_FOLD_ROWTOT : nullptr,
+                             l1 ? folded_l1 + ggd_fold_l1_offset(prm->P) : nullptr);
       if (rc != GGD_OK) return rc;
     }
   } else {

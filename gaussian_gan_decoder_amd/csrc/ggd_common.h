@@ -94,14 +94,19 @@ struct ggd_scan_piggy {
 constexpr int GGD_FOLD_REPS = 16;   // (32 / 16 / 8 replicas: 4114 / 4140 / 4150 frames per second at 1 M / 1024^2; 3907 workgroups over 8 would
                                     // keep one address busy 80 % of the kernel's time, 16 leaves a margin)
 constexpr int GGD_FOLD_REP_STRIDE = 4 * 256;
-constexpr int GGD_FOLD_HEAD = GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE + 64;   // words in front of the status words
+constexpr int GGD_FOLD_ROWTOT = GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE + 64;   // REPS x 64 words: entries per tile ROW (grids of <= 64
+                                                                           // rows), for the row binning's first level
+constexpr int GGD_FOLD_HEAD = GGD_FOLD_ROWTOT + GGD_FOLD_REPS * 64;        // words in front of the status words
 struct ggd_fold {
   uint32_t* ctl = nullptr;        // this frame's control block (clean)
   uint32_t* clear = nullptr;      // the other block ...
   uint32_t clear_words = 0;       // ... and how much of it the preprocess clears for the next frame
   uint2* wg_info = nullptr;       // [ceil(P / 256)]
+  int rows = 0;                   // != 0: also count the Gaussians per tile row (the grid has <= 64 rows)
 };
+// control block: [head | sort status words of the 4 passes | level-1 binning status words]
 size_t ggd_fold_ctl_words(int64_t P);
+size_t ggd_fold_l1_offset(int64_t P);   // first word of the level-1 status words
 
 int ggd_fail(ggd_ctx* ctx, int code, const std::string& msg);
 int ggd_reserve_scratch(ggd_ctx* ctx, size_t bytes, hipStream_t stream);
@@ -181,9 +186,11 @@ size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity, int W, int H);
 int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect, const uint32_t* order,
                       const uint32_t* n_vis_ptr, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
                       size_t tmp_bytes, const uint32_t* order_alt = nullptr, const uint32_t* use_alt = nullptr,
-                      const ggd_scan_piggy* apply = nullptr);   // apply: step 3 of a riding scan, as appended workgroups of the
+                      const ggd_scan_piggy* apply = nullptr, const uint32_t* fold_rowtot = nullptr, uint32_t* fold_status1 = nullptr);   // apply: step 3 of a riding scan, as appended workgroups of the
                                                                  // last (longest) binning launch
                       // *use_alt != 0 (device): the depth order is in order_alt (see ggd_launch_sort32_iota)
+                      // fold_rowtot / fold_status1 (folded front end, grids of <= 64 x 64 tiles): the entries per tile row were
+                      // counted by the preprocess kernel -- level 1 is ONE launch (count, look-back over the chunks, scatter)
 int ggd_launch_ranges(ggd_ctx* ctx, hipStream_t s, const uint64_t* keys, int64_t n, uint32_t* ranges, int T);
 int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const ggd_splat* splat,
                      const uint32_t* list, const uint32_t* ranges, uint32_t capacity, float* out_color, float* final_T,

@@ -31,9 +31,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     ggd_fold fold) {
   __shared__ uint32_t s_hist[FOLD ? 4 * 256 : 1];
   __shared__ uint32_t s_red[FOLD ? 8 : 1];
+  __shared__ int s_rowdiff[FOLD ? 65 : 1];
   if constexpr (FOLD) {
     for (uint32_t z = blockIdx.x * 256 + threadIdx.x; z < fold.clear_words; z += gridDim.x * 256) fold.clear[z] = 0u;
     for (int b = threadIdx.x; b < 4 * 256; b += 256) s_hist[b] = 0u;
+    if (threadIdx.x < 65) s_rowdiff[threadIdx.x] = 0;
     __syncthreads();
   } else {
     // first kernel of a frame: its first workgroups also clear the depth sort's control block (no memset launch there)
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   const bool in_range = i < P;
   if (!FOLD && !in_range) return;
   int irad = 0;
-  uint32_t ntiles = 0;
+  uint32_t ntiles = 0, rect_rows = 0;   // rect_rows = miny | maxy << 16 of a visible Gaussian
   bool visible = false;
   float depth = 0.0f;
   if (in_range) {
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   tiles_touched[i] = ntiles;
   depth_keys[i] = visible ? __float_as_uint(t[2]) : 0xFFFFFFFFu;
   rect[i] = rect_out;
+  rect_rows = rect_out.y;
   if (clamped) clamped[i] = (uint8_t)clamp_bits;
   if (visible) {
     float4* dst = reinterpret_cast<float4*>(splat + i);
@@ -202,6 +205,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         }
       }
     }
+    // (d) grids of <= 64 tile rows: entries per row for the row binning's first level -- difference array over the rows the
+    //     Gaussian's rect covers, prefix over the lanes after the barrier
+    if (fold.rows && visible) {
+      atomicAdd(&s_rowdiff[rect_rows & 0xffffu], 1);
+      atomicAdd(&s_rowdiff[rect_rows >> 16], -1);
+    }
     uint32_t tsum = ntiles;
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) tsum += __shfl_xor(tsum, sh, 64);
@@ -211,6 +220,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     for (int b = threadIdx.x; b < 4 * 256; b += 256) {
       const uint32_t c = s_hist[b];
       if (c) atomicAdd(&hist[b], c);
+    }
+    if (fold.rows && threadIdx.x < 64) {
+      int c = s_rowdiff[lane];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(c, d, 64); if (lane >= d) c += o; }
+      if (c) atomicAdd(&fold.ctl[GGD_FOLD_ROWTOT + (blockIdx.x % GGD_FOLD_REPS) * 64 + lane], (uint32_t)c);
     }
     if (threadIdx.x == 0)
       fold.wg_info[blockIdx.x] = make_uint2(s_red[0] + s_red[1] + s_red[2] + s_red[3], s_red[4] + s_red[5] + s_red[6] + s_red[7]);

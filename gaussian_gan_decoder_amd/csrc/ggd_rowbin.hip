@@ -231,6 +231,115 @@ __global__ __launch_bounds__(RB_THREADS) void rb_scatter1_kernel(const uint2* __
   });
 }
 
+// ---- level 1 in ONE launch (folded front end: the entries per row were counted by the preprocess kernel, GGD_FOLD_ROWTOT):
+//      count, decoupled look-back over the earlier chunks (lane = row; status words [chunk][64] then [group][64], zero at
+//      launch, bit 30 = published -- the scheme of the depth sort's passes), scatter.  Replaces rb_count1 / rb_scan1 /
+//      rb_scatter1 and the `packed` round trip between them.  Every workgroup derives the row starts from the 64 x REPS row
+//      totals itself; workgroup 0 also writes the tables level 2 reads.  Workgroups wait only for lower-numbered ones, which
+//      the dispatcher started earlier.
+constexpr uint32_t RB_PUB = 1u << 30;
+constexpr int RB_LB_BATCH = 16;
+__device__ __forceinline__ uint32_t rb_ld(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void rb_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// sum of `cnt` published words p[0], p[64], ...: RB_LB_BATCH requests in flight, unpublished ones are polled
+__device__ __forceinline__ uint32_t rb_sum_words(uint32_t* p, int cnt) {
+  uint32_t acc = 0;
+  for (int b0 = 0; b0 < cnt; b0 += RB_LB_BATCH) {
+    uint32_t v[RB_LB_BATCH];
+#pragma unroll
+    for (int i = 0; i < RB_LB_BATCH; ++i) v[i] = (b0 + i < cnt) ? rb_ld(p + (size_t)(b0 + i) * 64) : RB_PUB;
+#pragma unroll
+    for (int i = 0; i < RB_LB_BATCH; ++i) {
+      uint32_t x = v[i];
+      if ((x >> 30) == 0u) {
+        uint32_t* q = p + (size_t)(b0 + i) * 64;
+        do { __builtin_amdgcn_s_sleep(1); x = rb_ld(q); } while ((x >> 30) == 0u);
+      }
+      acc += x & (RB_PUB - 1u);
+    }
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(RB_THREADS) void rb_level1_kernel(const uint2* __restrict__ rect, const uint32_t* __restrict__ order,
+                                                               const uint32_t* __restrict__ n_vis_ptr, int P,
+                                                               const uint32_t* __restrict__ rowtot, uint32_t* status,
+                                                               int chunks_max, int gshift_max, uint32_t* __restrict__ tab,
+                                                               uint2* __restrict__ ent, uint32_t ent_cap,
+                                                               const uint32_t* __restrict__ order_alt,
+                                                               const uint32_t* __restrict__ use_alt) {
+  __shared__ int diff[RB_WAVES][65];
+  __shared__ uint32_t wcnt[RB_WAVES][64];
+  __shared__ uint32_t s_base[64];
+  if (use_alt && *use_alt != 0u) order = order_alt;   // the depth sort's last pass was the identity and copied nothing
+  const uint32_t n_vis = min((uint32_t)P, *n_vis_ptr);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  uint32_t rowstart = 0;
+  if (wv == 0) {
+    uint32_t tot = 0;
+#pragma unroll
+    for (int r = 0; r < GGD_FOLD_REPS; ++r) tot += rowtot[r * 64 + lane];
+    const uint32_t inc = wave_incl_scan_u32(tot);
+    rowstart = inc - tot;
+    if (blockIdx.x == 0) {   // the tables of level 2 (as rb_scan1_kernel writes them)
+      tab[RB_TAB_ROWSTART + lane] = rowstart;
+      if (lane == 63) tab[RB_TAB_ROWSTART + 64] = inc;
+      const uint32_t have = rowstart < ent_cap ? min(tot, ent_cap - rowstart) : 0u;
+      const uint32_t nblk = (have + RB_CHUNK - 1) / RB_CHUNK;
+      const uint32_t binc = wave_incl_scan_u32(nblk);
+      tab[RB_TAB_ROWBLK + lane] = binc - nblk;
+      if (lane == 63) tab[RB_TAB_ROWBLK + 64] = binc;
+      tab[RB_TAB_FLAG + lane] = 0u;   // consumed by rb_scan2_kernel
+    }
+  }
+  const uint32_t base = (uint32_t)blockIdx.x * RB_CHUNK;
+  if (base >= n_vis) return;
+  for (int i = tid; i < RB_WAVES * 65; i += RB_THREADS) (&diff[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t wbeg = base + (uint32_t)wv * RB_WCHUNK;
+  const int n_items = (int)min((uint32_t)RB_WCHUNK, n_vis > wbeg ? n_vis - wbeg : 0u);
+  uint32_t iv[RB_IPL], pa[RB_IPL], pb[RB_IPL];
+#pragma unroll
+  for (int q = 0; q < RB_IPL; ++q) {
+    const int i = q * 64 + lane;
+    pa[q] = 0; pb[q] = 0; iv[q] = 0;
+    if (i < n_items) {
+      const uint32_t id = order[wbeg + i];
+      const uint2 rc = rect[id];   // {minx | maxx << 16, miny | maxy << 16}
+      const uint32_t x0 = rc.x & 0xffffu, x1 = rc.x >> 16, y0 = rc.y & 0xffffu, y1 = rc.y >> 16;
+      pa[q] = id;
+      if ((int)(x1 - x0) * (int)(y1 - y0) > 0) { pb[q] = x0 | (x1 << 8); iv[q] = y0 | (y1 << 8); }
+    }
+  }
+  const uint32_t mine = wave_bin_counts(diff[wv], iv);
+  wcnt[wv][lane] = mine;
+  __syncthreads();
+  if (wv == 0) {
+    const uint32_t local = wcnt[0][lane] + wcnt[1][lane] + wcnt[2][lane] + wcnt[3][lane];
+    const int chunk = (int)blockIdx.x;
+    const int live = (int)((n_vis + RB_CHUNK - 1) / RB_CHUNK);   // group size ~ sqrt(live chunks), never above the launch's
+    int gs = 2;
+    while ((1 << (2 * gs)) < live) ++gs;
+    gs = min(gs, gshift_max);
+    const int grp = chunk >> gs, mem = chunk & ((1 << gs) - 1);
+    uint32_t* cw = status + lane;                              // [chunk][64]
+    uint32_t* gw = status + (size_t)chunks_max * 64 + lane;    // [group][64]
+    rb_st(cw + (size_t)chunk * 64, RB_PUB | local);
+    const uint32_t in_group = rb_sum_words(cw + ((size_t)grp << gs) * 64, mem);
+    if (mem == (1 << gs) - 1) rb_st(gw + (size_t)grp * 64, RB_PUB | (in_group + local));
+    s_base[lane] = rowstart + in_group + rb_sum_words(gw, grp);
+  }
+  __syncthreads();
+  uint32_t dst = s_base[lane];
+#pragma unroll
+  for (int w = 0; w < RB_WAVES; ++w) if (w < wv) dst += wcnt[w][lane];
+  wave_emit<true>(iv, pa, pb, n_items, dst, [&](uint32_t d, uint32_t id, uint32_t xx) {
+    if (d < ent_cap) ent[d] = make_uint2(id, xx);
+  });
+}
+
 // level-2 block -> (row, chunk within the row)
 // (one load per lane + a ballot: a binary search over the table is six DEPENDENT global loads, which was most of a
 // level-2 workgroup's lifetime)
@@ -412,7 +521,8 @@ size_t ggd_rowbin_tmp_bytes(int P, uint32_t capacity, int W, int H) {
 // capacity: upper bound on num_rendered (the level-1 entry count is <= num_rendered); order = depth-sorted ids.
 int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const uint2* rect, const uint32_t* order,
                       const uint32_t* n_vis_ptr, uint32_t* list, uint32_t* ranges, uint32_t capacity, void* tmp,
-                      size_t tmp_bytes, const uint32_t* order_alt, const uint32_t* use_alt, const ggd_scan_piggy* apply) {
+                      size_t tmp_bytes, const uint32_t* order_alt, const uint32_t* use_alt, const ggd_scan_piggy* apply,
+                      const uint32_t* fold_rowtot, uint32_t* fold_status1) {
   if (!ggd_rowbin_supported(prm.width, prm.height)) return ggd_fail(ctx, GGD_E_INVALID, "tile grid too large for row binning");
   if (tmp_bytes < ggd_rowbin_tmp_bytes(prm.P, capacity, prm.width, prm.height)) return ggd_fail(ctx, GGD_E_INVALID, "rowbin tmp too small");
   const int gx = (prm.width + 15) / 16, gy = (prm.height + 15) / 16;
@@ -445,11 +555,18 @@ int ggd_launch_rowbin(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const 
   uint32_t* counts2 = reinterpret_cast<uint32_t*>(p);
   const int nb1 = rb_blocks1(prm.P);
   const uint32_t nb2 = rb_blocks2(capacity);
-  hipLaunchKernelGGL(rb_count1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, prm.width, prm.height, rect, order,
-                     n_vis_ptr, prm.P, packed, counts1, order_alt, use_alt);
-  hipLaunchKernelGGL(rb_scan1_kernel, dim3(1), dim3(1024), 0, s, counts1, n_vis_ptr, prm.P, tab, capacity);
-  hipLaunchKernelGGL(rb_scatter1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, packed, n_vis_ptr, prm.P, counts1, tab,
-                     ent, capacity);
+  if (fold_rowtot && fold_status1) {
+    int gsm = 2;
+    while ((1 << (2 * gsm)) < nb1) ++gsm;   // (= rs_gshift(nb1): the group words were laid out for it, ggd_fold_ctl_words)
+    hipLaunchKernelGGL(rb_level1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, rect, order, n_vis_ptr, prm.P, fold_rowtot,
+                       fold_status1, nb1, gsm, tab, ent, capacity, order_alt, use_alt);
+  } else {
+    hipLaunchKernelGGL(rb_count1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, prm.width, prm.height, rect, order,
+                       n_vis_ptr, prm.P, packed, counts1, order_alt, use_alt);
+    hipLaunchKernelGGL(rb_scan1_kernel, dim3(1), dim3(1024), 0, s, counts1, n_vis_ptr, prm.P, tab, capacity);
+    hipLaunchKernelGGL(rb_scatter1_kernel, dim3(nb1), dim3(RB_THREADS), 0, s, packed, n_vis_ptr, prm.P, counts1, tab,
+                       ent, capacity);
+  }
   hipLaunchKernelGGL(rb_count2_kernel, dim3(nb2), dim3(RB_THREADS), 0, s, ent, capacity, tab, counts2);
   hipLaunchKernelGGL(rb_scan2_kernel, dim3(gy), dim3(1024), 0, s, counts2, tab, gx, gy, ranges);
   static_assert(RB_THREADS == SCAN_THREADS, "the appended scan workgroups share the launch's block size");

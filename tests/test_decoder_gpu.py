@@ -29,6 +29,29 @@ def test_triplane_mean_matches_torch(native_lib, C, H, W, N):
     assert (planes.grad - ref_planes.grad).abs().max().item() <= 1e-5 * scale * 10   # fp32 atomics: order-dependent sums
 
 
+def test_sorted_scatter_with_a_live_tile_count_just_below_a_power_of_four(native_lib):
+    """3 N = 1 048 800 items = 257 tiles of the depth-sort kernels, of which 600 items (200 points far outside the box) are
+    dropped: 256 LIVE tiles.  A pass sizes its look-back groups from the live count (16 groups of 16) while the status words
+    were laid out for the launched count (9 group rows until round 4: the surplus rows overwrote the next pass's tile words and
+    the order -- hence the run accumulation of the gradient -- came out wrong)."""
+    dev = torch.device("cuda:0")
+    N, C, H, W = 349_600, 32, 64, 64
+    g = torch.Generator().manual_seed(99)
+    planes = torch.randn(3, C, H, W, generator=g).to(dev).requires_grad_(True)
+    pos = torch.rand(N, 3, generator=g) * 0.9 - 0.45
+    pos[torch.randperm(N, generator=g)[:200]] = 5.0
+    pos = pos.to(dev)
+    ref_planes = planes.detach().clone().requires_grad_(True)
+    out = triplane_mean(planes, pos, 1.0)
+    ref = sample_from_planes(ref_planes, pos, 1.0).mean(0)
+    assert (out - ref).abs().max().item() <= 1e-5
+    gout = torch.randn(N, C, generator=g).to(dev)
+    out.backward(gout)
+    ref.backward(gout)
+    scale = max(1.0, ref_planes.grad.abs().max().item())
+    assert (planes.grad - ref_planes.grad).abs().max().item() <= 1e-4 * scale
+
+
 def _trigrid_reference64(planes, pos, axes, D, mod=None):
     """float64 autograd through torch's own 3-D grid_sample on the CPU: features and d(sum(features * gout)) / d planes."""
     p64 = planes.detach().double().cpu().requires_grad_(True)
