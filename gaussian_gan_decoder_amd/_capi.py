@@ -44,6 +44,7 @@ class ImgView(C.Structure):
 
 
 OPT_EXP_MODE, OPT_BLEND_CULL, OPT_BINNING, OPT_BLEND_SPLIT, OPT_FOLD = 0, 1, 2, 3, 4
+STAT_FLAT_STREAK, STAT_SORT_RERUNS = 100, 101   # read-only, through get_option
 SPLAT_BYTES = 48
 SPLAT_FIELDS = ("x", "y", "hA", "nB", "hC", "thr", "opacity", "r", "g", "b", "ex", "ey")
 

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
   __shared__ uint32_t s_cnt[4][RS_BINS];   // per-wave running digit counts -> per-wave scatter bases
   if ((int)blockIdx.x >= ntiles) {   // appended workgroups: steps 2 / 3 of the offsets scan (see ggd_scan_piggy)
     if (piggy_role == 2 && pg.wg_info) {
-      scan_info_block(pg.wg_info, pg.n_info, pg.block_sums, pg.n_valid, pg.d_total, pg.h_total, &s_cnt[0][0], pg.h_tagged, pg.tag);
+      const uint2 tv = scan_info_block(pg.wg_info, pg.n_info, pg.block_sums, pg.n_valid, pg.d_total, pg.h_total, &s_cnt[0][0]);
+      int flat = 0;
       if (pg.fold_hist) {   // passes 1 .. 3 then read ONE histogram (pass 0's tiles, running beside us, read their own 256 bins
                             // of every replica: reading all replicas cost each pass ~2 us)
         uint32_t acc[3] = {0u, 0u, 0u};
@@ -252,7 +253,18 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
           for (int p = 1; p < 4; ++p) acc[p - 1] += pg.fold_hist[r * GGD_FOLD_REP_STRIDE + p * RS_BINS + threadIdx.x];
         }
 #pragma unroll
-        for (int p = 1; p < 4; ++p) pg.fold_hist[p * RS_BINS + threadIdx.x] += acc[p - 1];
+        for (int p = 1; p < 4; ++p) {
+          acc[p - 1] += pg.fold_hist[p * RS_BINS + threadIdx.x];
+          pg.fold_hist[p * RS_BINS + threadIdx.x] = acc[p - 1];
+        }
+        flat = __syncthreads_or(acc[2] == tv.y);   // the top digit of every kept key is the same (also: nothing kept)
+      }
+      if (threadIdx.x == 0) {
+        if (pg.spec_flat && pg.flat_flag) *pg.flat_flag = 1u;
+        if (pg.d_total) pg.d_total[2] = (uint32_t)flat;
+        if (pg.h_tagged)   // one 64-bit store: the host sees tag, flag and total together
+          __hip_atomic_store(pg.h_tagged, ((unsigned long long)flat << 63) | ((unsigned long long)(pg.tag & 0x7fffffffu) << 32) | tv.x,
+                             __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     else if (piggy_role == 2)
@@ -542,7 +554,7 @@ size_t ggd_fold_ctl_words(int64_t P) {   // + level-1 binning: one 64-word row p
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
                            uint32_t* clean_ctl, const ggd_scan_piggy* piggy, bool flag_flat_last, bool apply_here,
-                           const ggd_fold* fold) {
+                           const ggd_fold* fold, bool skip_last) {
   if (n <= 0) return GGD_OK;
   const int passes = sort_passes(nbits);
   if (passes > RS_MAX_PASSES || (passes & 1)) return ggd_fail(ctx, GGD_E_INVALID, "sort32: need an even pass count");
@@ -567,7 +579,8 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
   // the offsets scan rides on the first three launches as appended workgroups (reduce | block sums | apply)
   ggd_scan_piggy pg = piggy ? *piggy : ggd_scan_piggy{};
   const int pnb = piggy ? pg.nb : 0;
-  if (fold) { pg.n_valid = n_valid; pg.fold_hist = ghist; }   // (pass 0 does not read n_valid: its appended workgroup writes it
+  if (skip_last && !(fold && flag_flat_last)) return ggd_fail(ctx, GGD_E_INVALID, "sort32: skip_last needs the folded front end");
+  if (fold) { pg.n_valid = n_valid; pg.fold_hist = ghist; pg.flat_flag = tickets + RS_MAX_PASSES + 1; pg.spec_flat = skip_last ? 1 : 0; }   // (pass 0 does not read n_valid: its appended workgroup writes it
                                                               // -- and sums the replicas -- for the later passes)
   if (!fold) {
     // (tile size of this launch, measured at 1 M keys: 4 / 16 / 32 / 64 keys per thread = 977 / 245 / 123 / 62 workgroups flushing
@@ -582,7 +595,7 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
   // pass 0: keys_src (read-only, caller's buffer) -> B with identity values; then B -> A -> B -> A ...
   const uint32_t* kin = keys_src;
   const uint32_t* vin = nullptr;
-  for (int p = 0; p < passes; ++p) {
+  for (int p = 0; p < passes - (skip_last ? 1 : 0); ++p) {
     uint32_t* kout = (p & 1) ? keys_a : keys_b;
     uint32_t* vout = (p & 1) ? vals_a : vals_b;
     if (p == 0)

@@ -198,6 +198,8 @@ extern "C" int ggd_blend_timeline(ggd_ctx* ctx, unsigned long long* out, int wav
 }
 
 extern "C" int ggd_get_option(ggd_ctx* ctx, int option) {
+  if (ctx && option == GGD_STAT_FLAT_STREAK) return ctx->flat_streak;
+  if (ctx && option == GGD_STAT_SORT_RERUNS) return (int)(ctx->spec3_misses & 0x7fffffffull);
   if (!ctx || option < 0 || option >= GGD_OPT_COUNT) return GGD_E_INVALID;
   return ctx->opt[option];
 }
@@ -376,17 +378,18 @@ static int geometry_finish(ggd_ctx* ctx, void* stream, const ggd_params* prm, in
     // call's tag (an event record behind that launch would cost the GPU a ~6 us bubble between two kernels).  Every few
     // thousand polls the stream is queried: if it has drained without the tag (a failed launch), fall back to the copy.
     volatile unsigned long long* slot = reinterpret_cast<volatile unsigned long long*>(ctx->h_words + 2);
-    const unsigned long long want = ctx->r_tag;
+    const unsigned long long want = ctx->r_tag;   // (31 bits; bit 63 of the word: this frame's top depth digit is constant)
     unsigned long long v = *slot;
-    for (unsigned spins = 0; (v >> 32) != want; ++spins) {
+    for (unsigned spins = 0; ((v >> 32) & 0x7fffffffull) != want; ++spins) {
       __builtin_ia32_pause();
       if ((spins & 0xfff) == 0xfff) {
         const hipError_t q = hipStreamQuery(static_cast<hipStream_t>(stream));
         if (q == hipSuccess) {
           v = *slot;
-          if ((v >> 32) != want) {
-            GGD_HIP(hipMemcpy(ctx->h_words, ctx->d_words, sizeof(uint32_t), hipMemcpyDeviceToHost));
-            v = (want << 32) | ctx->h_words[0];
+          if (((v >> 32) & 0x7fffffffull) != want) {
+            uint32_t w3[3] = {0u, 0u, 0u};
+            GGD_HIP(hipMemcpy(w3, ctx->d_words, sizeof(w3), hipMemcpyDeviceToHost));
+            v = ((unsigned long long)(w3[2] & 1u) << 63) | (want << 32) | w3[0];
           }
           break;
         }
@@ -396,6 +399,7 @@ static int geometry_finish(ggd_ctx* ctx, void* stream, const ggd_params* prm, in
       v = *slot;
     }
     ctx->h_words[0] = (uint32_t)v;
+    ctx->frame_flat = (v >> 63) != 0ull;
   } else {
     GGD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   }
@@ -490,7 +494,9 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
         pg.n = prm->P; pg.nb = ggd_scan_blocks(prm->P); pg.block_sums = ctx->scan_sums;
         pg.d_total = ctx->d_words; pg.h_total = ctx->h_words_dev;
         pg.h_tagged = reinterpret_cast<unsigned long long*>(ctx->h_words_dev + 2);
-        pg.tag = ++ctx->r_tag;
+        ctx->r_tag = (ctx->r_tag + 1u) & 0x7fffffffu;
+        if (ctx->r_tag == 0u) ctx->r_tag = 1u;
+        pg.tag = ctx->r_tag;
         if (folded) {
           const int nwg = (prm->P + 255) / 256;
           fold.ctl = ctx->foldctl[ctx->fold_cur ^ 1];   // (fold_cur already points at the next frame's block)
@@ -501,8 +507,12 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
       }
       ctx->fold_active = false;
       riding = ctx->scan_deferred;
+      // the fourth pass is an empty launch when the depths' top byte is constant: after GGD_FLAT_STREAK such frames it is not
+      // launched; ggd_forward re-renders a frame for which that was wrong (frame_flat arrives with num_rendered)
+      ctx->frame_folded = folded;
+      ctx->spec3 = folded && rowbin && speculative && ctx->flat_streak >= GGD_FLAT_STREAK && ctx->opt[GGD_OPT_FOLD] == 1;
       rc = ggd_launch_sort32_iota(ctx, s, depth_keys, ka, va, kb, vb, prm->P, 32, tmp, sort_tmp, folded ? nullptr : clean_ctl,
-                                  riding ? &pg : nullptr, rowbin, !rowbin, folded ? &fold : nullptr);
+                                  riding ? &pg : nullptr, rowbin, !rowbin, folded ? &fold : nullptr, ctx->spec3);
       ctx->r_pending = riding && rc == GGD_OK;
       ctx->scan_deferred = false;
       if (rc != GGD_OK) return rc;
@@ -591,12 +601,20 @@ extern "C" int ggd_forward(ggd_ctx* ctx, void* stream, const ggd_params* prm, co
   if (prm->P == 0) return render_enqueue(ctx, stream, prm, geom_buf, capacity, 0, binning_buf, img_buf, out_color, false);
   if (ggd_forward_can_speculate(ctx, prm, capacity)) {
     // everything is enqueued before the host waits: the GPU never idles on the num_rendered read-back
+    ctx->spec3 = false; ctx->frame_folded = false; ctx->frame_flat = false;
     rc = render_enqueue(ctx, stream, prm, geom_buf, capacity, capacity, binning_buf, img_buf, out_color, true);
     if (rc != GGD_OK) return rc;
     rc = geometry_finish(ctx, stream, prm, num_rendered);
     if (rc != GGD_OK) return rc;
+    const bool spec3 = ctx->spec3;
+    ctx->spec3 = false;
+    if (ctx->frame_folded) ctx->flat_streak = ctx->frame_flat ? ctx->flat_streak + 1 : 0;
     if (*num_rendered > capacity)
       return ggd_fail(ctx, GGD_E_CAPACITY, "binning_buf capacity is below num_rendered: re-run with a larger buffer");
+    if (spec3 && !ctx->frame_flat) {   // three sort passes were not enough for this frame: bin and blend it again, in full
+      ctx->spec3_misses += 1;
+      return render_enqueue(ctx, stream, prm, geom_buf, capacity, *num_rendered, binning_buf, img_buf, out_color, false);
+    }
     return GGD_OK;
   }
   rc = geometry_finish(ctx, stream, prm, num_rendered);

@@ -45,6 +45,14 @@ struct ggd_ctx {
   size_t foldctl_dirty[2] = {0, 0}; // words of each block its last user may have written (what the next clear must cover)
   int fold_cur = 0;                 // block the next folding preprocess accumulates into (cleared by the previous one)
   bool fold_active = false;         // this call's preprocess left histograms + workgroup sums for the sort of the same call
+  // the depth keys' top byte (sign + 7 exponent bits) is constant in most scenes: after GGD_FLAT_STREAK such frames in a row
+  // the fourth sort pass -- an empty launch, 4.9 us -- is not launched at all; the frame's own histogram says whether that
+  // was right (bit 63 of the tagged num_rendered word), and a frame it was wrong for is binned and blended again
+  int flat_streak = 0;
+  bool spec3 = false;               // this call launched three passes
+  bool frame_flat = false;          // this call's top byte was constant (read with num_rendered)
+  bool frame_folded = false;        // ... and it ran the folded front end (frame_flat is meaningful)
+  unsigned long long spec3_misses = 0;
   bool scan_deferred = false;       // geometry_enqueue left the scan to the sort launches of the same call
   void* gelu_tables = nullptr;      // GELU / GELU' interpolation tables of the reference-precision decoder kernels (built on first use)
   uint32_t r_tag = 0;               // sequence number of the single-call forward whose num_rendered the host is waiting for
@@ -81,6 +89,8 @@ struct ggd_scan_piggy {
   int n_info = 0;
   uint32_t* n_valid = nullptr;              // receives the number of kept keys (sum of wg_info[].y)
   int sum_stride = 1;                       // block_sums entries per scan block of step 3 (8 with wg_info: 2048 / 256)
+  uint32_t* flat_flag = nullptr;            // folded front end: "the order is in the third pass's output" word of the consumers
+  int spec_flat = 0;                        // != 0: only three passes were launched -- set *flat_flag whatever the histogram says
   uint32_t* fold_hist = nullptr;            // the folded front end's histogram replicas: the workgroup that runs step 2 also adds
                                             // replicas 1 .. REPS-1 of passes 1 .. 3 into replica 0 (only pass 0 reads them all)
 };
@@ -171,12 +181,17 @@ int ggd_launch_sort(ggd_ctx* ctx, hipStream_t s, uint64_t* keys_a, uint32_t* val
 int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
                            uint32_t* keys_b, uint32_t* vals_b, int64_t n, int nbits, void* tmp, size_t tmp_bytes,
                            uint32_t* clean_ctl = nullptr, const ggd_scan_piggy* piggy = nullptr,
-                           bool flag_flat_last = false, bool apply_here = true, const ggd_fold* fold = nullptr);
+                           bool flag_flat_last = false, bool apply_here = true, const ggd_fold* fold = nullptr,
+                           bool skip_last = false);
 // flag_flat_last: a constant-digit LAST pass copies nothing -- it sets the word ggd_sort32_flat_ptr(ctl) and the result
 //                 stays in (keys_b, vals_b)
 // apply_here = false: the caller runs the riding scan's last step (offsets) elsewhere -- ggd_launch_rowbin(apply = ...)
 // fold: histograms, kept-key count and the scan's step 1 come from the preprocess kernel (piggy must carry wg_info); no
-//       histogram launch
+//       histogram launch.  The workgroup that runs the scan's step 2 reports "top digit constant" in bit 63 of the tagged
+//       num_rendered word and in d_total[2].
+// skip_last (fold only): the last pass is not launched (the caller expects a constant top digit); the consumers' flat word is
+//       set regardless, so that they read the third pass's output (a valid permutation either way)
+constexpr int GGD_FLAT_STREAK = 8;
 const uint32_t* ggd_sort32_flat_ptr(const void* ctl);
 const uint32_t* ggd_fold_nvalid_ptr(const uint32_t* fold_ctl);   // the same two words of a folded front end's control block
 const uint32_t* ggd_fold_flat_ptr(const uint32_t* fold_ctl);

@@ -226,6 +226,14 @@ int ggd_set_option(ggd_ctx* ctx, int option, int value);
 int ggd_blend_stats(ggd_ctx* ctx, int enable, unsigned long long* out);
 int ggd_blend_timeline(ggd_ctx* ctx, unsigned long long* out, int waves);
 int ggd_get_option(ggd_ctx* ctx, int option);
+/* Read-only counters through ggd_get_option (single-call forward with GGD_OPT_FOLD = 1): the depth keys' top byte is constant in
+ * most scenes, which makes the fourth sort pass an empty launch; after 8 such frames in a row it is not launched, every
+ * frame's own histogram says whether that held, and a frame for which it did not is binned and blended again before
+ * ggd_forward returns (results are identical either way). */
+enum {
+  GGD_STAT_FLAT_STREAK = 100,   /* consecutive frames whose top depth digit was constant */
+  GGD_STAT_SORT_RERUNS = 101    /* frames re-rendered because three sort passes were not enough */
+};
 
 /*
  * Tri-plane feature gather of the per-point decoder (input side of the raster path; replaces the three torch ops

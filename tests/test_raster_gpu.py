@@ -371,3 +371,40 @@ def test_folded_sort_front_end_across_scenes_of_different_size_and_depth_range(n
             np.testing.assert_array_equal(n["point_offsets"], o["point_offsets"])
             np.testing.assert_array_equal(n["point_list"], o["point_list"])
             np.testing.assert_array_equal(n["ranges"], o["ranges"])
+
+
+def test_fourth_sort_pass_is_skipped_after_a_streak_and_a_wrong_guess_is_rendered_again(native_lib):
+    """Depths inside one pair of binades make the depth keys' top byte constant and the fourth sort pass an empty launch: after
+    8 such single-call frames in a row it is not launched.  A scene whose depths span several binades then gets three passes
+    where it needs four -- the frame's own histogram says so, ggd_forward bins and blends it again, and the streak restarts.
+    Every frame must match the oracle's lists bit for bit."""
+    from gaussian_gan_decoder_amd import _capi
+    ctx = _capi.context_for(torch.device("cuda:0"))
+    near = scene_inputs(P=20000, size=128, lsm=-4.5, seed=21)
+    deep = scene_inputs(P=20000, size=128, lsm=-4.5, seed=22)
+    g = torch.Generator().manual_seed(23)
+    deep["means3D"] = (deep["means3D"] * torch.exp(3.0 * torch.rand(20000, 1, generator=g))).contiguous()
+    o_near, o_deep = run_oracle(near), run_oracle(deep)
+    dn, dd = o_near["depths"][o_near["radii"] > 0], o_deep["depths"][o_deep["radii"] > 0]
+    top = lambda d: np.unique(d.astype(np.float32).view(np.uint32) >> 24)
+    assert len(top(dn)) == 1 and len(top(dd)) > 1          # the premise: constant / varying top byte
+
+    def check(d, o):
+        n = run_native(d, debug=False)
+        assert n["num_rendered"] == o["num_rendered"]
+        np.testing.assert_array_equal(n["point_list"], o["point_list"])
+        np.testing.assert_array_equal(n["ranges"], o["ranges"])
+    check(near, o_near); check(deep, o_deep)               # two-call form first (capacity hints for the shape)
+    check(deep, o_deep)                                    # single-call, four passes: resets the streak
+    assert ctx.get_option(_capi.STAT_FLAT_STREAK) == 0
+    reruns = ctx.get_option(_capi.STAT_SORT_RERUNS)
+    for k in range(12):
+        check(near, o_near)
+        assert ctx.get_option(_capi.STAT_FLAT_STREAK) == k + 1
+    assert ctx.get_option(_capi.STAT_SORT_RERUNS) == reruns       # frames 9 .. 12 ran three passes, rightly
+    check(deep, o_deep)                                            # three passes, wrongly: rendered again
+    assert ctx.get_option(_capi.STAT_SORT_RERUNS) == reruns + 1 and ctx.get_option(_capi.STAT_FLAT_STREAK) == 0
+    check(deep, o_deep)                                            # four passes again
+    assert ctx.get_option(_capi.STAT_SORT_RERUNS) == reruns + 1
+    check(near, o_near)
+    assert ctx.get_option(_capi.STAT_FLAT_STREAK) == 1
