@@ -412,7 +412,7 @@ def main():
             stage_ms[k] = v / nprof
     ctx.set_profiling(False)
 
-    # ---- BASELINE config 3: decode ~1M Gaussians (tri-plane gather + fused bf16-MFMA decoder) and render at 1024^2
+    # ---- BASELINE config 3: decode ~1M Gaussians (tri-plane gather + fused f16-MFMA decoder) and render at 1024^2
     decode = None
     if not args.no_decode and rank == 0:
         from gaussian_gan_decoder_amd.decoder import SequentialDecoderReverse, triplane_mean
@@ -494,7 +494,7 @@ def main():
         mlp_flops = 2 * 192512 * 1_000_000
         decode = {"frames_per_s": 1.0 / td, "ms_per_frame": td * 1e3, "frames_per_s_two_in_flight": 1.0 / td2,
                   "points": 1_000_000, "image": "1024x1024",
-                  "pipeline": "tri-plane gather (HIP) -> fused 5-head decoder (bf16 MFMA) -> HIP raster (activation prologue fused)",
+                  "pipeline": "tri-plane gather (HIP) -> fused 5-head decoder (f16 MFMA, packed-f16 GELU) -> HIP raster (activation prologue fused)",
                   "mlp_ms": tm * 1e3, "mlp_TFLOPs": mlp_flops / tm / 1e12,
                   "mlp_frac_of_bf16_dense_peak": mlp_flops / tm / 2.5e15,
                   "mlp_fp32_accurate_ms": tm32 * 1e3}
@@ -577,7 +577,8 @@ def main():
         # (2) SURVEY 8f row 1: decoder forward / activation backward / weight gradients as bf16-MFMA HIP kernels
         #     (fp32 accumulate, fp32 master weights and optimizer) -- reported beside (1), never instead of it
         train_fused = run_train(True)
-        train_fused["mlp_dtype"] = "bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16)"
+        train_fused["mlp_dtype"] = ("16-bit operands, fp32 accumulate: forward f16 (v_mfma_f32_16x16x32_f16, z kept as f16), activation backward "
+                                    "and weight gradients bf16 (v_mfma_f32_16x16x32_bf16)")
         train_fused["step"] = ("plane gather (HIP, per-scene modulation fused) -> fused 5-head decoder (HIP MFMA fwd, bwd, split-K wgrad; all "
                                "local scenes in one launch) -> HIP raster fwd -> " + LOSS + " -> bwd -> "
                                "bucketed flat all-reduce launched from gradient hooks, per-bucket Adam")
@@ -589,7 +590,7 @@ def main():
         #     parameter gradients within 1e-3 (relative L2; measured 1e-4 .. 3e-4) of a float64 evaluation (tests/test_decoder_gpu.py)
         train_fused_fp32 = run_train(True, precision="fp32")
         train_fused_fp32["mlp_dtype"] = ("fp32-accurate: split bf16 operands (hi + lo), 3 x v_mfma_f32_16x16x32_bf16 per product, "
-                                         "fp32 accumulate; pre-activations z kept as one fp16 plane, dz as two bf16 planes (hi | lo)")
+                                         "fp32 accumulate; pre-activations z kept as one fp16 plane, dz as one fp16 plane scaled per (head, 32-point slab)")
         train_fused_fp32["step"] = train_fused["step"].replace("HIP MFMA fwd", "HIP MFMA at reference precision: fwd")
         train_fused_fp32["eg3d_planes"] = run_train(True, precision="fp32", planes="eg3d")
         del batches
@@ -604,7 +605,7 @@ def main():
     dom_s = stage_ms[dom] * 1e-3
     achieved = dom_bytes / dom_s / 1e9
     whole = sum(algorithmic_bytes(k, P, num_rendered, S, S) for k in fwd_stages)
-    path_bytes = (algorithmic_bytes("preprocess", P, num_rendered, S, S) + 4 * P + 3 * 16 * p_vis + 8 * row_entries
+    path_bytes = (algorithmic_bytes("preprocess", P, num_rendered, S, S) + 4 * P + 8 * p_vis + 2 * 16 * p_vis + 8 * row_entries
                   + 4 * num_rendered + algorithmic_bytes("blend", P, num_rendered, S, S))
     ms_per_step = elapsed / args.steps * 1e3
     result = {
@@ -633,9 +634,10 @@ def main():
                      "valu_wave_insts": pmc_valu(args.workload, dom)},
         "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
         "frame_ms_percentiles": {k: (round(v, 5) if k != "n" else v) for k, v in frame_pct.items()},
-        # whole frame against HBM: `algorithmic_bytes_path` = what THIS path has to move (preprocess; depth sort of the visible
-        # Gaussians: 4 B / Gaussian for the histogram + 16 B / visible Gaussian for each of its 3 non-constant passes; 8 B per
-        # (Gaussian, tile row) entry; 4 B / instance for the list; the blend) -> frac_of_hbm_peak.  SURVEY 8d's contract formula,
+        # whole frame against HBM: `algorithmic_bytes_path` = what THIS path has to move (preprocess, which also builds the sort's
+        # histograms; depth sort of the visible Gaussians: the first pass reads 4 B / Gaussian and writes 8 B / visible one, the
+        # two further non-constant passes 16 B / visible Gaussian each; 8 B per (Gaussian, tile row) entry; 4 B / instance for
+        # the list; the blend) -> frac_of_hbm_peak.  SURVEY 8d's contract formula,
         # which prices the reference's 6-pass 64-bit sort of all instances that this path does not run, is kept beside it.
         "whole_frame": {"algorithmic_bytes_path": path_bytes, "GBps": path_bytes / (ms_per_step * 1e-3) / 1e9,
                         "frac_of_hbm_peak": path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
