@@ -584,7 +584,7 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
                                                               // -- and sums the replicas -- for the later passes)
   if (!fold) {
     // (tile size of this launch, measured at 1 M keys: 4 / 16 / 32 / 64 keys per thread = 977 / 245 / 123 / 62 workgroups flushing
-    // into the same 1024 words: 50.4 / 19.2 / 19.3 / 29.1 us -- same-address atomics retire at ~43 ns each)
+    // into the same 1024 words: 50.4 / 19.2 / 19.3 / 29.1 us -- atomic instructions on one 64-byte line serialise, ~43 ns per 16 lanes)
     const int htiles = ntiles;
     hipLaunchKernelGGL((sort_global_hist_kernel<uint32_t, RS32_ITEMS, true>), dim3(htiles + pnb), dim3(RS_THREADS), 0, s,
                        keys_src, n, passes, ghist, n_valid, clean_ctl ? status : nullptr,

@@ -98,7 +98,7 @@ struct ggd_scan_piggy {
 // The depth sort's histogram kernel folded into the preprocess kernel (single-call forward on the tile-binning path): every
 // preprocess workgroup adds the digit counts of its kept depth keys to one of GGD_FOLD_REPS replicas of the four 256-bin
 // histograms and stores {sum of tiles_touched, kept keys} of its 256 points -- the histogram launch (19 us at 1 M points:
-// its 245 workgroups flush into 1024 words, and same-address atomics retire at ~43 ns each on this part) and
+// its 245 workgroups flush into the same 64 lines, and atomic instructions on one line serialise at ~43 ns per 16 lanes) and
 // step 1 of the offsets scan disappear.  Control block (words): [REPS * 1024 histograms | 8 tickets | n_valid | flat | pad
 // to 64 | status words of the 4 passes]; two blocks alternate, each cleared by the preprocess of the frame before its use.
 constexpr int GGD_FOLD_REPS = 16;   // (32 / 16 / 8 replicas: 4114 / 4140 / 4150 frames per second at 1 M / 1024^2; 3907 workgroups over 8 would
