@@ -316,6 +316,12 @@ def main():
             fif[str(nslots)] = {"frames_per_s": nf / tf, "ms_per_frame": tf / nf * 1e3}
             del streams, outs
         extra["frames_in_flight"] = fif
+    # the single-call forward's front end: histograms + scan step 1 + row counts inside the preprocess
+    # kernel, the fourth sort pass not launched after a streak of frames whose top depth byte was constant (verified per frame;
+    # a frame it was wrong for is binned and blended again: `sort_reruns`)
+    extra["forward_path"] = {"fold": ctx.get_option(_capi.OPT_FOLD), "flat_streak": ctx.get_option(_capi.STAT_FLAT_STREAK),
+                             "sort_reruns": ctx.get_option(_capi.STAT_SORT_RERUNS),
+                             "kernel_launches_per_frame": 9 if ctx.get_option(_capi.OPT_FOLD) and S <= 1024 else None}
     if not args.no_sweep and rank == 0:
         # the other synthetic configurations of BASELINE.json's north_star ({100k, 1M} x {512, 1024}), forward raster only,
         # 100 frames each -- reported for the table in DESIGN.md; the headline `value` is the workload above
