@@ -927,7 +927,7 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
                      uint32_t* n_contrib) {
   const int gx = (prm.width + 15) / 16, gy = (prm.height + 15) / 16;
   if (gx * gy == 0) return GGD_OK;
-  const int em = ctx->opt[GGD_OPT_EXP_MODE];
+  const int em = ctx->opt[GGD_OPT_EXP_MODE] == 3 ? 1 : ctx->opt[GGD_OPT_EXP_MODE];   // 3 (default): bare v_exp_f32 in the forward
   const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
   const int T = gx * gy;
 #define GGD_LAUNCH_FWD2(EM, CU, ST)                                                                                     \
@@ -953,7 +953,7 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
                               const uint32_t* n_contrib, const float* dL_dpix, float* grad_acc) {
   const int gx = (prm.width + 15) / 16, gy = (prm.height + 15) / 16;
   if (gx * gy == 0) return GGD_OK;
-  const int em = ctx->opt[GGD_OPT_EXP_MODE];
+  const int em = ctx->opt[GGD_OPT_EXP_MODE] == 3 ? 2 : ctx->opt[GGD_OPT_EXP_MODE];   // 3 (default): compensated 2^x in the backward
   const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
   const int T = gx * gy;
   int split = ctx->opt[GGD_OPT_BLEND_SPLIT];

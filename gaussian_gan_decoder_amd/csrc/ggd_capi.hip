@@ -108,7 +108,7 @@ extern "C" ggd_ctx* ggd_create(int device) {
   ggd_ctx* ctx = new (std::nothrow) ggd_ctx();
   if (!ctx) { ggd_fail(nullptr, GGD_E_NOMEM, "out of host memory"); return nullptr; }
   ctx->device = device;
-  if (const char* e = getenv("GGD_EXP_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->opt[GGD_OPT_EXP_MODE] = v; }
+  if (const char* e = getenv("GGD_EXP_MODE")) { const int v = atoi(e); if (v >= 0 && v <= 3) ctx->opt[GGD_OPT_EXP_MODE] = v; }
   if (const char* e = getenv("GGD_BINNING")) { const int v = atoi(e); if (v >= 0 && v <= 3) ctx->opt[GGD_OPT_BINNING] = v; }
   if (const char* e = getenv("GGD_BLEND_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 4) ctx->opt[GGD_OPT_BLEND_SPLIT] = v; }
   if (const char* e = getenv("GGD_BLEND_CULL")) ctx->opt[GGD_OPT_BLEND_CULL] = atoi(e) != 0;
@@ -166,7 +166,7 @@ extern "C" const char* ggd_last_error(ggd_ctx* ctx) { return ctx ? ctx->err.c_st
 
 extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
   if (!ctx) return GGD_E_INVALID;
-  static const int kMax[GGD_OPT_COUNT] = {2, 1, 3, 4, 1};
+  static const int kMax[GGD_OPT_COUNT] = {3, 1, 3, 4, 1};
   if (option < 0 || option >= GGD_OPT_COUNT || value < 0 || value > kMax[option])
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_set_option: unknown option or value");
   ctx->opt[option] = value;

@@ -270,7 +270,8 @@ def test_wide_grid_row_binning_survives_capacity_overflow(native_lib, W, H):
 def test_blend_options_do_not_change_the_image(native_lib):
     """Wave-level culling (GGD_OPT_BLEND_CULL) is an exact optimisation: image, final_T and n_contrib are bit-identical
     with it on or off, also on a grid whose tile count is not a multiple of 8 (the other workgroup -> tile mapping).  The
-    exp variants (GGD_OPT_EXP_MODE 0/1/2) may differ by ulps only: <= 1e-5 against each other."""
+    exp variants (GGD_OPT_EXP_MODE 0/1/2, and 3 = the default: 1 in the forward, 2 in the backward) may differ by ulps only:
+    <= 1e-5 against each other."""
     from gaussian_gan_decoder_amd import _capi
     cx = _capi.context_for(torch.device("cuda:0"))
     saved = [cx.get_option(o) for o in (_capi.OPT_EXP_MODE, _capi.OPT_BLEND_CULL)]
@@ -288,7 +289,7 @@ def test_blend_options_do_not_change_the_image(native_lib):
         d = scene_inputs(P=20000, size=256, kind="shell", lsm=-4.5)
         cx.set_option(_capi.OPT_BLEND_CULL, saved[1])
         base = run_native(d, debug=False)
-        for em in (0, 1, 2):
+        for em in (0, 1, 2, 3):
             cx.set_option(_capi.OPT_EXP_MODE, em)
             n = run_native(d, debug=False)
             same = n["n_contrib"] == base["n_contrib"]
