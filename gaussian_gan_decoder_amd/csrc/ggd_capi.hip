@@ -316,6 +316,13 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
       ctx->foldctl_cap = cap;
       ctx->fold_cur = 0;
     }
+    if (ctx->fold_poisoned) {
+      for (int b = 0; b < 2; ++b) {
+        GGD_HIP(hipMemsetAsync(ctx->foldctl[b], 0, ctx->foldctl_cap * sizeof(uint32_t), s));
+        ctx->foldctl_dirty[b] = 0;
+      }
+      ctx->fold_poisoned = false;
+    }
     const int cur = ctx->fold_cur, oth = cur ^ 1;
     fold.ctl = ctx->foldctl[cur];
     fold.clear = ctx->foldctl[oth];
@@ -334,7 +341,7 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
                                cov3D_precomp, splat, tiles, shs ? clamped : nullptr, radii, depth_keys, rect,
                                ctx->d_words + 1, old_ctl ? ctx->sortctl : nullptr, old_ctl ? (int)ggd_sort_ctrl_words() : 0,
                                ctx->fold_active ? &fold : nullptr);
-    if (rc != GGD_OK) { ctx->fold_active = false; return rc; }
+    if (rc != GGD_OK) { ctx->fold_poisoned = ctx->fold_active; ctx->fold_active = false; return rc; }
     ctx->sortctl_clean = old_ctl;
   }
   ctx->scan_deferred = false;

@@ -44,6 +44,7 @@ struct ggd_ctx {
   size_t foldctl_cap = 0;           // words per block
   size_t foldctl_dirty[2] = {0, 0}; // words of each block its last user may have written (what the next clear must cover)
   int fold_cur = 0;                 // block the next folding preprocess accumulates into (cleared by the previous one)
+  bool fold_poisoned = false;       // a folding launch failed: nothing is known about the blocks -- clear both before the next use
   bool fold_active = false;         // this call's preprocess left histograms + workgroup sums for the sort of the same call
   // the depth keys' top byte (sign + 7 exponent bits) is constant in most scenes: after GGD_FLAT_STREAK such frames in a row
   // the fourth sort pass -- an empty launch, 4.9 us -- is not launched at all; the frame's own histogram says whether that
