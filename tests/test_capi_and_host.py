@@ -21,6 +21,18 @@ def test_library_exports_every_declared_symbol(native_lib):
         assert hasattr(native_lib, sym), f"libggd_raster.so does not export {sym}"
 
 
+def test_option_and_counter_constants_match_the_header():
+    """_capi's OPT_* / STAT_* numbers are the enum values of include/ggd_raster.h (the binding passes them as plain ints)."""
+    import os
+    import re
+    from gaussian_gan_decoder_amd import _capi
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ggd_raster.h")).read()
+    val = lambda name: int(re.search(r"\b" + name + r"\s*=\s*(\d+)", hdr).group(1))
+    assert (_capi.OPT_EXP_MODE, _capi.OPT_BLEND_CULL, _capi.OPT_BINNING, _capi.OPT_BLEND_SPLIT, _capi.OPT_FOLD) == tuple(
+        val(n) for n in ("GGD_OPT_EXP_MODE", "GGD_OPT_BLEND_CULL", "GGD_OPT_BINNING", "GGD_OPT_BLEND_SPLIT", "GGD_OPT_FOLD"))
+    assert (_capi.STAT_FLAT_STREAK, _capi.STAT_SORT_RERUNS) == (val("GGD_STAT_FLAT_STREAK"), val("GGD_STAT_SORT_RERUNS"))
+
+
 def test_layouts_and_sort_bits(native_lib):
     from gaussian_gan_decoder_amd import _capi
     assert C.sizeof(_capi.Params) == 80
