@@ -616,7 +616,7 @@ extern "C" int ggd_forward(ggd_ctx* ctx, void* stream, const ggd_params* prm, co
     if (rc != GGD_OK) return rc;
     const bool spec3 = ctx->spec3;
     ctx->spec3 = false;
-    if (ctx->frame_folded) ctx->flat_streak = ctx->frame_flat ? ctx->flat_streak + 1 : 0;
+    if (ctx->frame_folded) ctx->flat_streak = ctx->frame_flat ? (ctx->flat_streak < (1 << 30) ? ctx->flat_streak + 1 : ctx->flat_streak) : 0;
     if (*num_rendered > capacity)
       return ggd_fail(ctx, GGD_E_CAPACITY, "binning_buf capacity is below num_rendered: re-run with a larger buffer");
     if (spec3 && !ctx->frame_flat) {   // three sort passes were not enough for this frame: bin and blend it again, in full
