@@ -316,6 +316,26 @@ def main():
             fif[str(nslots)] = {"frames_per_s": nf / tf, "ms_per_frame": tf / nf * 1e3}
             del streams, outs
         extra["frames_in_flight"] = fif
+        # ... and with rasterizer.FramePipeline (ggd_forward_enqueue / ggd_forward_collect): the host does not wait for a
+        # frame's num_rendered before it launches the next one -- it is collected when the slot comes round again
+        pfl = {}
+        for nslots in (2, 3, 4):
+            pipe = R.FramePipeline(dev, slots=nslots)
+            for i in range(6 * nslots):
+                pipe.submit(*fargs)
+            pipe.drain()
+            torch.cuda.synchronize(dev)
+            nf = max(200, args.steps)
+            tf = time.perf_counter()
+            for i in range(nf):
+                pipe.submit(*fargs)
+            rest = pipe.drain()
+            torch.cuda.synchronize(dev)
+            tf = time.perf_counter() - tf
+            assert all(r[0] == num_rendered and torch.equal(r[1], out[1]) for r in rest), "pipelined frames differ"
+            pfl[str(nslots)] = {"frames_per_s": nf / tf, "ms_per_frame": tf / nf * 1e3, "synchronous_frames": pipe.synchronous_frames}
+            del pipe, rest
+        extra["frames_in_flight_pipelined"] = pfl
     # the single-call forward's front end: histograms + scan step 1 + row counts inside the preprocess
     # kernel, the fourth sort pass not launched after a streak of frames whose top depth byte was constant (verified per frame;
     # a frame it was wrong for is binned and blended again: `sort_reruns`)

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("GGD_LIB_PATH") or os.path.join(_PKG, "libggd_raster.s
 EXPORTS = [
     "ggd_geom_bytes", "ggd_binning_bytes", "ggd_img_bytes", "ggd_geom_layout", "ggd_binning_layout",
     "ggd_img_layout", "ggd_sort_bits", "ggd_create", "ggd_destroy", "ggd_last_error", "ggd_version",
-    "ggd_forward_geometry", "ggd_forward_render", "ggd_forward", "ggd_forward_can_speculate", "ggd_backward", "ggd_mark_visible", "ggd_debug_unsorted",
+    "ggd_forward_geometry", "ggd_forward_render", "ggd_forward", "ggd_forward_enqueue", "ggd_forward_collect", "ggd_forward_can_speculate", "ggd_backward", "ggd_mark_visible", "ggd_debug_unsorted",
     "ggd_triplane_forward", "ggd_triplane_backward", "ggd_trigrid_forward", "ggd_trigrid_backward", "ggd_planes_gather", "ggd_planes_scatter", "ggd_surface_tmp_bytes", "ggd_surface_sample", "ggd_attrs_split", "ggd_attrs_merge", "ggd_decoder_packed_bytes", "ggd_decoder_pack", "ggd_decoder_forward", "ggd_decoder_zbuf_bytes", "ggd_decoder_packed_t_bytes",
     "ggd_decoder_forward_train", "ggd_decoder_backward", "ggd_decoder_wgrad_floats", "ggd_decoder_wgrad", "ggd_decoder_backward_wgrad", "ggd_decoder_packed_hl_bytes", "ggd_decoder_packed_t_hl_bytes", "ggd_decoder_dzbuf_hl_bytes", "ggd_decoder_pack_hl", "ggd_decoder_forward_hl", "ggd_decoder_backward_wgrad_hl", "ggd_image_loss_tmp_bytes", "ggd_image_loss", "ggd_set_option", "ggd_get_option", "ggd_blend_stats", "ggd_blend_timeline", "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
 ]
@@ -79,6 +79,8 @@ def load():
         lib.ggd_forward_geometry.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 7 + [vp, vp, C.POINTER(i64)]
         lib.ggd_forward_render.argtypes = [vp, vp, C.POINTER(Params), vp, i64, vp, vp, vp]
         lib.ggd_forward.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 7 + [vp, vp, vp, i64, vp, vp, C.POINTER(i64)]
+        lib.ggd_forward_enqueue.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 7 + [vp, vp, vp, i64, vp, vp]
+        lib.ggd_forward_collect.argtypes = [vp, vp, C.POINTER(i64)]
         lib.ggd_forward_can_speculate.argtypes = [vp, C.POINTER(Params), i64]
         lib.ggd_backward.argtypes = [vp, vp, C.POINTER(Params)] + [vp] * 7 + [vp, vp, vp, vp, i64, vp] + [vp] * 8
         lib.ggd_mark_visible.argtypes = [vp, vp, i32, vp, vp, vp, vp]

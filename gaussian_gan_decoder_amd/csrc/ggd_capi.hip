@@ -596,40 +596,83 @@ extern "C" int ggd_forward_can_speculate(ggd_ctx* ctx, const ggd_params* prm, in
           (bmode == 2 || bmode == 3 || (bmode == 1 && capacity >= GGD_ROWBIN_MIN_R))) ? 1 : 0;
 }
 
+// The speculative route of the single-call forward in its two halves: everything is enqueued before the host looks at
+// num_rendered (the GPU never idles on that read-back) ...
+static int forward_spec_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D, const float* shs,
+                                const float* colors_precomp, const float* opacities, const float* scales,
+                                const float* rotations, const float* cov3D_precomp, void* geom_buf, int32_t* radii,
+                                void* binning_buf, int64_t capacity, void* img_buf, float* out_color, int64_t* num_rendered) {
+  int rc = geometry_enqueue(ctx, stream, prm, means3D, shs, colors_precomp, opacities, scales, rotations,
+                            cov3D_precomp, geom_buf, radii, num_rendered, true);
+  if (rc != GGD_OK) return rc;
+  ctx->spec3 = false; ctx->frame_folded = false; ctx->frame_flat = false;
+  return render_enqueue(ctx, stream, prm, geom_buf, capacity, capacity, binning_buf, img_buf, out_color, true);
+}
+// ... and the collection of num_rendered (+ "the depth keys' top byte was constant") once the launch that delivers it has run;
+// binning and blend may still be running.  A frame that needed the fourth sort pass it did not get is binned and blended again.
+static int forward_spec_collect(ggd_ctx* ctx, void* stream, const ggd_params* prm, const void* geom_buf, void* binning_buf,
+                                int64_t capacity, void* img_buf, float* out_color, int64_t* num_rendered) {
+  int rc = geometry_finish(ctx, stream, prm, num_rendered);
+  if (rc != GGD_OK) return rc;
+  const bool spec3 = ctx->spec3;
+  ctx->spec3 = false;
+  if (ctx->frame_folded) ctx->flat_streak = ctx->frame_flat ? (ctx->flat_streak < (1 << 30) ? ctx->flat_streak + 1 : ctx->flat_streak) : 0;
+  if (*num_rendered > capacity)
+    return ggd_fail(ctx, GGD_E_CAPACITY, "binning_buf capacity is below num_rendered: re-run with a larger buffer");
+  if (spec3 && !ctx->frame_flat) {   // three sort passes were not enough for this frame: bin and blend it again, in full
+    ctx->spec3_misses += 1;
+    return render_enqueue(ctx, stream, prm, geom_buf, capacity, *num_rendered, binning_buf, img_buf, out_color, false);
+  }
+  return GGD_OK;
+}
+
 extern "C" int ggd_forward(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, const float* cov3D_precomp, void* geom_buf, int32_t* radii,
                            void* binning_buf, int64_t capacity, void* img_buf, float* out_color,
                            int64_t* num_rendered) {
   if (capacity < 0) return ggd_fail(ctx, GGD_E_INVALID, "capacity < 0");
-  const bool spec = prm && prm->P > 0 && ggd_forward_can_speculate(ctx, prm, capacity) != 0;
+  if (ctx) ctx->pending.valid = false;
+  if (prm && prm->P > 0 && capacity > 0 && ggd_forward_can_speculate(ctx, prm, capacity)) {
+    const int rc = forward_spec_enqueue(ctx, stream, prm, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                        cov3D_precomp, geom_buf, radii, binning_buf, capacity, img_buf, out_color, num_rendered);
+    if (rc != GGD_OK) return rc;
+    return forward_spec_collect(ctx, stream, prm, geom_buf, binning_buf, capacity, img_buf, out_color, num_rendered);
+  }
   int rc = geometry_enqueue(ctx, stream, prm, means3D, shs, colors_precomp, opacities, scales, rotations,
-                            cov3D_precomp, geom_buf, radii, num_rendered, spec && capacity > 0);
+                            cov3D_precomp, geom_buf, radii, num_rendered, false);
   if (rc != GGD_OK) return rc;
   if (prm->P == 0) return render_enqueue(ctx, stream, prm, geom_buf, capacity, 0, binning_buf, img_buf, out_color, false);
-  if (ggd_forward_can_speculate(ctx, prm, capacity)) {
-    // everything is enqueued before the host waits: the GPU never idles on the num_rendered read-back
-    ctx->spec3 = false; ctx->frame_folded = false; ctx->frame_flat = false;
-    rc = render_enqueue(ctx, stream, prm, geom_buf, capacity, capacity, binning_buf, img_buf, out_color, true);
-    if (rc != GGD_OK) return rc;
-    rc = geometry_finish(ctx, stream, prm, num_rendered);
-    if (rc != GGD_OK) return rc;
-    const bool spec3 = ctx->spec3;
-    ctx->spec3 = false;
-    if (ctx->frame_folded) ctx->flat_streak = ctx->frame_flat ? (ctx->flat_streak < (1 << 30) ? ctx->flat_streak + 1 : ctx->flat_streak) : 0;
-    if (*num_rendered > capacity)
-      return ggd_fail(ctx, GGD_E_CAPACITY, "binning_buf capacity is below num_rendered: re-run with a larger buffer");
-    if (spec3 && !ctx->frame_flat) {   // three sort passes were not enough for this frame: bin and blend it again, in full
-      ctx->spec3_misses += 1;
-      return render_enqueue(ctx, stream, prm, geom_buf, capacity, *num_rendered, binning_buf, img_buf, out_color, false);
-    }
-    return GGD_OK;
-  }
   rc = geometry_finish(ctx, stream, prm, num_rendered);
   if (rc != GGD_OK) return rc;
   if (*num_rendered > capacity)
     return ggd_fail(ctx, GGD_E_CAPACITY, "binning_buf capacity is below num_rendered: re-run with a larger buffer");
   return render_enqueue(ctx, stream, prm, geom_buf, capacity, *num_rendered, binning_buf, img_buf, out_color, false);
+}
+
+extern "C" int ggd_forward_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D, const float* shs,
+                                   const float* colors_precomp, const float* opacities, const float* scales,
+                                   const float* rotations, const float* cov3D_precomp, void* geom_buf, int32_t* radii,
+                                   void* binning_buf, int64_t capacity, void* img_buf, float* out_color) {
+  if (!ctx) return GGD_E_INVALID;
+  if (ctx->pending.valid) return ggd_fail(ctx, GGD_E_INVALID, "ggd_forward_enqueue: the previous frame of this context has not been collected");
+  if (!prm || prm->P <= 0 || capacity <= 0 || !ggd_forward_can_speculate(ctx, prm, capacity))
+    return ggd_fail(ctx, GGD_E_INVALID, "ggd_forward_enqueue needs the tile-binning path, P > 0 and a capacity (ggd_forward_can_speculate)");
+  int64_t dummy = 0;
+  const int rc = forward_spec_enqueue(ctx, stream, prm, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                      cov3D_precomp, geom_buf, radii, binning_buf, capacity, img_buf, out_color, &dummy);
+  if (rc != GGD_OK) return rc;
+  ctx->pending.valid = true; ctx->pending.prm = *prm; ctx->pending.geom = geom_buf; ctx->pending.binning = binning_buf;
+  ctx->pending.capacity = capacity; ctx->pending.img = img_buf; ctx->pending.out = out_color;
+  return GGD_OK;
+}
+
+extern "C" int ggd_forward_collect(ggd_ctx* ctx, void* stream, int64_t* num_rendered) {
+  if (!ctx || !num_rendered) return GGD_E_INVALID;
+  if (!ctx->pending.valid) return ggd_fail(ctx, GGD_E_INVALID, "ggd_forward_collect: no frame is pending on this context");
+  ctx->pending.valid = false;
+  return forward_spec_collect(ctx, stream, &ctx->pending.prm, ctx->pending.geom, ctx->pending.binning, ctx->pending.capacity,
+                              ctx->pending.img, ctx->pending.out, num_rendered);
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------

@@ -54,6 +54,9 @@ struct ggd_ctx {
   bool frame_flat = false;          // this call's top byte was constant (read with num_rendered)
   bool frame_folded = false;        // ... and it ran the folded front end (frame_flat is meaningful)
   unsigned long long spec3_misses = 0;
+  // ggd_forward_enqueue ... ggd_forward_collect: the frame whose num_rendered has not been collected yet
+  struct { bool valid = false; ggd_params prm; const void* geom = nullptr; void* binning = nullptr; int64_t capacity = 0;
+           void* img = nullptr; float* out = nullptr; } pending;
   bool scan_deferred = false;       // geometry_enqueue left the scan to the sort launches of the same call
   void* gelu_tables = nullptr;      // GELU / GELU' interpolation tables of the reference-precision decoder kernels (built on first use)
   uint32_t r_tag = 0;               // sequence number of the single-call forward whose num_rendered the host is waiting for

@@ -197,6 +197,116 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
     return int(R.value), color, radii, geom, binning, img
 
 
+class FramePipeline:
+    """Several forward frames in flight on one GPU: `slots` HIP streams, each with its own rasterizer context, used round-robin.
+    `submit(...)` takes the arguments of `rasterize_gaussians_native`, launches the whole frame on the next slot's stream with
+    `ggd_forward_enqueue` and returns WITHOUT waiting for its num_rendered -- the latency-bound front of that frame (per-Gaussian
+    kernel, depth sort, binning: about one workgroup per CU) then runs under the blend of the frame before it.  What it returns
+    is the result of the frame that used the slot last (None while the pipeline fills): the tuple of
+    `rasterize_gaussians_native` plus a `torch.cuda.Event` recorded behind that frame -- make the consuming stream
+    `wait_event` it (or synchronise) before reading the tensors.  `drain()` returns the results still pending, oldest first.
+
+    The slot's stream first waits for the stream that is current at `submit`, so inputs produced there are safe to use.  A
+    frame for which no capacity hint exists yet (first frame of a shape), a `debug` frame, or one whose binning overflowed
+    its capacity is rendered through the ordinary synchronous path on the slot's stream; results are identical either way."""
+
+    def __init__(self, device, slots: int = 2):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("FramePipeline needs a HIP device (there is no CPU fallback)")
+        self.slots = [dict(stream=torch.cuda.Stream(device=self.device), pending=None) for _ in range(max(1, int(slots)))]
+        self._next = 0
+        self.synchronous_frames = 0     # frames that took the ordinary path (no hint yet / overflow / unsupported)
+
+    def _collect(self, slot):
+        pend = slot["pending"]
+        if pend is None:
+            return None
+        slot["pending"] = None
+        with torch.cuda.stream(slot["stream"]):
+            if "result" in pend:                      # rendered synchronously at submit time
+                res = pend["result"]
+            else:
+                ctx, handle = _capi.context_and_stream(self.device)
+                R = C.c_int64(0)
+                rc = ctx.lib.ggd_forward_collect(ctx.handle, C.c_void_p(handle), C.byref(R))
+                if rc == -6:                          # GGD_E_CAPACITY: this frame's outputs are not valid -- render it again
+                    ctx.capacity_retries += 1
+                    ctx.capacity_hint[pend["key"]] = max(int(R.value), ctx.capacity_hint.get(pend["key"]) or 0)
+                    self.synchronous_frames += 1
+                    res = rasterize_gaussians_native(*pend["args"])
+                else:
+                    ctx.check(rc)
+                    hint = ctx.capacity_hint.get(pend["key"]) or 0
+                    ctx.capacity_hint[pend["key"]] = max(int(R.value), int(hint * _HINT_DECAY))
+                    res = (int(R.value),) + pend["outputs"]
+            ev = torch.cuda.Event()
+            ev.record(slot["stream"])
+        return res + (ev,)
+
+    def submit(self, bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+               projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
+               raw_attributes=False):
+        args = (bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+                tanfovx, tanfovy, image_height, image_width, sh, degree, campos, prefiltered, debug, raw_attributes)
+        slot = self.slots[self._next]
+        self._next = (self._next + 1) % len(self.slots)
+        prev = self._collect(slot)
+        _require_cuda(means3D)
+        dev = means3D.device
+        slot["stream"].wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(slot["stream"]):
+            P = means3D.size(0)
+            H, W = int(image_height), int(image_width)
+            ctx, handle = _capi.context_and_stream(dev)
+            key = (P, W, H)
+            hint = ctx.capacity_hint.get(key)
+            if hint is None or P == 0 or debug:
+                self.synchronous_frames += 1
+                slot["pending"] = dict(result=rasterize_gaussians_native(*args))
+                return prev
+            means3D_c = _f32c(means3D, "means3D", dev)
+            opac_c = _f32c(opacities, "opacities", dev)
+            have = lambda t: t is not None and t.numel() > 0
+            sh_c = _f32c(sh, "sh", dev) if have(sh) else None
+            col_c = _f32c(colors_precomp, "colors_precomp", dev) if have(colors_precomp) else None
+            sc_c = _f32c(scales, "scales", dev) if have(scales) else None
+            rot_c = _f32c(rotations, "rotations", dev) if have(rotations) else None
+            cov_c = _f32c(cov3D_precomp, "cov3D_precomp", dev) if have(cov3D_precomp) else None
+            M = sh_c.size(1) if sh_c is not None else 0
+            rs = GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix,
+                                               projmatrix, degree, campos, prefiltered, debug, raw_attributes)
+            keep: list = [means3D_c, opac_c, sh_c, col_c, sc_c, rot_c, cov_c]
+            prm = _params(rs, P, M, dev, keep)
+            cap = _capacity(hint)
+            lib = ctx.lib
+            if not lib.ggd_forward_can_speculate(ctx.handle, C.byref(prm), cap):
+                self.synchronous_frames += 1
+                slot["pending"] = dict(result=rasterize_gaussians_native(*args))
+                return prev
+            u8 = dict(dtype=torch.uint8, device=dev)
+            color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            geom = torch.empty((_sizes("g", P, 0),), **u8)
+            img = torch.empty((_sizes("i", W, H),), **u8)
+            binning = torch.empty((_sizes("b", cap, 0),), **u8)
+            with _device_guard(dev):
+                ctx.check(lib.ggd_forward_enqueue(ctx.handle, C.c_void_p(handle), C.byref(prm), _ptr(means3D_c), _ptr(sh_c),
+                                                  _ptr(col_c), _ptr(opac_c), _ptr(sc_c), _ptr(rot_c), _ptr(cov_c), _ptr(geom),
+                                                  _ptr(radii), _ptr(binning), cap, _ptr(img), _ptr(color)))
+            slot["pending"] = dict(outputs=(color, radii, geom, binning, img), key=key, args=args, keep=keep, prm=prm)
+        return prev
+
+    def drain(self):
+        out = []
+        n = len(self.slots)
+        for k in range(n):                      # oldest first: the slot that would be used next holds the oldest frame
+            res = self._collect(self.slots[(self._next + k) % n])
+            if res is not None:
+                out.append(res)
+        return out
+
+
 def rasterize_gaussians_backward_native(bg, means3D, radii, colors_precomp, scales, rotations, scale_modifier,
                                         cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, dL_dout_color, sh,
                                         degree, campos, geomBuffer, R, binningBuffer, imgBuffer, debug,

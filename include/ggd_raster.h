@@ -164,6 +164,21 @@ int ggd_forward(ggd_ctx* ctx, void* stream, const ggd_params* prm,
                 const float* scales, const float* rotations, const float* cov3D_precomp,
                 void* geom_buf, int32_t* radii, void* binning_buf, int64_t capacity, void* img_buf,
                 float* out_color, int64_t* num_rendered);
+
+/*
+ * The same forward in two halves, for hosts that keep several frames in flight (one context + stream per frame slot: the
+ * latency-bound front of frame k + 1 -- per-Gaussian kernel, depth sort, binning -- runs under the blend of frame k).
+ * ggd_forward_enqueue launches the whole frame and returns at once; it needs the speculative route (ggd_forward_can_speculate,
+ * P > 0, capacity > 0).  ggd_forward_collect, called any time later on the same context (typically when the slot comes round
+ * again, the frame long finished), returns that frame's num_rendered -- or GGD_E_CAPACITY with it, in which case the outputs
+ * are not valid and the frame has to be rendered again with a larger buffer.  At most one frame per context may be pending;
+ * the buffers, the camera matrices and the other pointers of `prm` must stay valid until it is collected.
+ */
+int ggd_forward_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm,
+                        const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                        const float* scales, const float* rotations, const float* cov3D_precomp,
+                        void* geom_buf, int32_t* radii, void* binning_buf, int64_t capacity, void* img_buf, float* out_color);
+int ggd_forward_collect(ggd_ctx* ctx, void* stream, int64_t* num_rendered);
 int ggd_forward_can_speculate(ggd_ctx* ctx, const ggd_params* prm, int64_t capacity);
 
 /*

@@ -409,3 +409,49 @@ def test_fourth_sort_pass_is_skipped_after_a_streak_and_a_wrong_guess_is_rendere
     assert ctx.get_option(_capi.STAT_SORT_RERUNS) == reruns + 1
     check(near, o_near)
     assert ctx.get_option(_capi.STAT_FLAT_STREAK) == 1
+
+
+@pytest.mark.parametrize("slots", [1, 2, 3])
+def test_frame_pipeline_returns_the_frames_of_the_ordinary_path(native_lib, slots):
+    """FramePipeline (ggd_forward_enqueue / ggd_forward_collect: several frames in flight, num_rendered collected a round later)
+    must return, frame for frame and bit for bit, what rasterize_gaussians_native returns -- over scenes of different size, a
+    scene that needs all four sort passes after a streak that dropped the fourth, and a frame that overflows its capacity."""
+    from gaussian_gan_decoder_amd import rasterizer as R
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.empty(0, device=dev) if x is None else x.to(dev)
+
+    def args_of(d):
+        return (t(d["bg"]), t(d["means3D"]), t(d["colors_precomp"]), t(d["opacities"]), t(d["scales"]), t(d["rotations"]),
+                d["scale_modifier"], t(d["cov3D_precomp"]), t(d["viewmatrix"]), t(d["projmatrix"]), d["tanfovx"], d["tanfovy"],
+                d["H"], d["W"], t(d["shs"]), d["sh_degree"], t(d["campos"]), False, False)
+    near = scene_inputs(P=20000, size=128, lsm=-4.5, seed=31)
+    small = scene_inputs(P=3000, size=128, lsm=-4.0, seed=32)
+    deep = scene_inputs(P=20000, size=128, lsm=-4.5, seed=33)
+    g = torch.Generator().manual_seed(34)
+    deep["means3D"] = (deep["means3D"] * torch.exp(3.0 * torch.rand(20000, 1, generator=g))).contiguous()
+    big = scene_inputs(P=20000, size=128, lsm=-3.2, seed=35)      # same shape as `near`, several times its instances
+    scenes = {k: args_of(d) for k, d in (("near", near), ("small", small), ("deep", deep), ("big", big))}
+    ref = {k: R.rasterize_gaussians_native(*a) for k, a in scenes.items()}
+    assert ref["big"][0] > 3 * ref["near"][0]
+    order = ["near", "small"] * 2 + ["near"] * 12 + ["deep", "near", "small", "deep", "deep"] + ["near"] * 3
+    pipe = R.FramePipeline(dev, slots=slots)
+    # (the hint of the shape shared by near / deep / big is dropped to near's size, so that `big` overflows its buffer)
+    from gaussian_gan_decoder_amd import _capi
+    got = []
+    for i, k in enumerate(order + ["big", "near", "near"]):
+        if k == "big":
+            for s_ in pipe.slots:
+                with torch.cuda.stream(s_["stream"]):
+                    _capi.context_and_stream(dev)[0].capacity_hint[(20000, 128, 128)] = ref["near"][0]
+        res = pipe.submit(*scenes[k])
+        if res is not None:
+            got.append(res)
+    got += pipe.drain()
+    names = order + ["big", "near", "near"]
+    assert len(got) == len(names)
+    assert pipe.synchronous_frames <= 4 * slots + 2      # (first frame of a shape on each slot's context, the overflow)
+    for k, res in zip(names, got):
+        res[-1].synchronize()
+        assert res[0] == ref[k][0], k
+        assert torch.equal(res[1], ref[k][1]), k              # image
+        assert torch.equal(res[2], ref[k][2]), k              # radii
