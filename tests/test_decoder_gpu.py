@@ -224,10 +224,12 @@ def test_fused_decoder_training_gradients(native_lib):
 
     def rel(a, b):
         return ((a - b).norm() / (a.norm() + 1e-12)).item()
-    assert rel(planes_a.grad, planes_b.grad) <= 5e-2
+    # bf16 activation gradients (dz) bound these; measured 4.6e-3 (planes) and <= 5.7e-3 (every parameter tensor) with the f16
+    # forward and the f16 z plane of round 4
+    assert rel(planes_a.grad, planes_b.grad) <= 1.5e-2
     for (na, pa), (nb, pb) in zip(ref.named_parameters(), fused_mod.named_parameters()):
         assert pb.grad is not None, nb
-        assert rel(pa.grad, pb.grad) <= 6e-2, (na, rel(pa.grad, pb.grad))
+        assert rel(pa.grad, pb.grad) <= 1.5e-2, (na, rel(pa.grad, pb.grad))
 
 
 def test_fused_decoder_matches_reference_class_fixture(native_lib):
