@@ -157,9 +157,9 @@ class Context:
     def blend_stats(self, enable):
         """Start (True / 1: work counters, 2: per-wave timeline) or stop (False) the forward-blend statistics; returns the
         counters gathered since the last start."""
-        out = (C.c_ulonglong * 5)()
+        out = (C.c_ulonglong * 6)()
         self.check(self.lib.ggd_blend_stats(self.handle, int(enable), out))
-        return dict(zip(("visited", "culled", "lanes", "pixels", "listed"), [int(v) for v in out]))
+        return dict(zip(("visited", "culled", "lanes", "pixels", "listed", "culled_in_loop"), [int(v) for v in out]))
 
     def blend_timeline(self, waves: int):
         """[waves, 4] int64 array: start tick, end tick (100 MHz), list length, entries gathered -- of the forward blend that

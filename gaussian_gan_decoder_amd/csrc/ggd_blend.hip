@@ -208,13 +208,17 @@ __device__ __forceinline__ void blend_forward_block(int blk, float4* s_rec, int 
                                                     float* __restrict__ final_T,
                                                     uint32_t* __restrict__ n_contrib,
                                                     unsigned long long* __restrict__ stats) {
+#ifndef GGD_FWD_GRP
+#define GGD_FWD_GRP 8
+#endif
+  constexpr int GRP = GGD_FWD_GRP;   // staged records per straight-line group
   const int lane = threadIdx.x;
   using Geom = WaveGeom<PXL, BW>;
   const Geom g(blk, gx, T, ranges, capacity);
   const bool row_in = g.py < H;
   float INF = __builtin_huge_valf();
   asm volatile("" : "+v"(INF));   // keep it in a VGPR (VOP3 selects take no 32-bit literal)
-  uint32_t st_visited = 0, st_culled = 0, st_lanes = 0, st_pixels = 0;  // wave-uniform debug counters (GGD stats)
+  uint32_t st_visited = 0, st_culled = 0, st_lanes = 0, st_pixels = 0, st_inloop = 0;  // wave-uniform debug counters (GGD stats)
   const uint64_t st_t0 = STATS ? wall_clock64() : 0ull;                // 100 MHz constant clock: the wave's residency
   float Tr[PXL], C[PXL][3];   // per pixel: transmittance, accumulated colour
   uint32_t last[PXL];
@@ -306,7 +310,7 @@ __device__ __forceinline__ void blend_forward_block(int blk, float4* s_rec, int 
     // last group (padding that group with records nobody can see cost their cull tests: 1 % of the kernel).  The blend
     // state is updated in place by the tied-operand selects below, inside a wave-uniform `if` -- nothing is copied where
     // the culled and the updated path join.
-    const int n = __popcll(kept), n8 = (n + 7) & ~7;
+    const int n = __popcll(kept), n8 = (n + GRP - 1) & ~(GRP - 1);
     if (STATS) {
       st_visited += min(64u, g.hi - base);
       st_culled += min(64u, g.hi - base) - (uint32_t)__popcll(kept);
@@ -314,7 +318,7 @@ __device__ __forceinline__ void blend_forward_block(int blk, float4* s_rec, int 
     load_rec(base + 64 + lane);    // next round's records (their list entries were requested one round ago)
     load_id(base + 128 + lane);    // and the list entries of the round after it
     __syncthreads();
-    for (int j0 = 0; j0 < n8; j0 += 8) {
+    for (int j0 = 0; j0 < n8; j0 += GRP) {
       if (!wave_alive()) goto all_done;
       // the group's LDS address, held in a VGPR the compiler cannot rematerialise: as a wave-uniform value it lives in an
       // SGPR and every ds_read whose destination overlapped the address register re-copied it (two v_mov per record:
@@ -322,18 +326,25 @@ __device__ __forceinline__ void blend_forward_block(int blk, float4* s_rec, int 
       uint32_t ga = (uint32_t)(uintptr_t)(lds_cf4*)(s_rec + j0 * 3);
       asm volatile("" : "+v"(ga));
       lds_cf4* grp = (lds_cf4*)(uintptr_t)ga;
-      // the six words the cull test of a record needs are requested one record ahead (before the previous record's
-      // test and update), so that the test does not start with an LDS round trip
-      float4 a_nx = lds_read4(grp);
-      float2 b_nx = lds_read2(grp + 1, 0);
+      // ALL twelve words of a record are requested one record ahead (round 5; round 4 prefetched the six words of the cull
+      // test and fetched the other six after the test had passed, 3 instructions before their first use -- an exposed LDS
+      // round trip per update, and since the exact rectangle pre-cull 95 % of the staged records are updates).  Inside a
+      // group only: carried across the group boundary the prefetched record is live on the loop's nine exit edges in
+      // alternating register sets, which the compiler reconciles with ~100 v_mov per group.
+      float4 a_nx = lds_read4(grp), b_nx = lds_read4(grp + 1), c_nx = lds_read4(grp + 2);
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
+      for (int jj = 0; jj < GRP; ++jj) {
         if (j0 + jj >= n) break;   // (scalar compare + branch: the last group of a round is usually not full)
-        const float4 a = a_nx;
-        const float2 b01 = b_nx;
-        if (jj < 7) {
+        const float4 a = a_nx, b4 = b_nx, c = c_nx;
+        // (the record's twelfth word is not used: left dead, the register allocator hands its VGPR out as a temporary while the
+        // load is still in flight, and the write-after-write hazard puts a wait for the whole prefetch three instructions
+        // behind its issue)
+        asm volatile("" : : "v"(c.w));
+        const float2 b01 = make_float2(b4.x, b4.y);
+        if (jj < GRP - 1) {
           a_nx = lds_read4(grp + (jj + 1) * 3);
-          b_nx = lds_read2(grp + (jj + 1) * 3 + 1, 0);
+          b_nx = lds_read4(grp + (jj + 1) * 3 + 1);
+          c_nx = lds_read4(grp + (jj + 1) * 3 + 2);
         }
         const float dy = a.y - pyf;
         const float nBdy = a.w * dy, hCdy2 = (b01.x * dy) * dy;
@@ -346,15 +357,14 @@ __device__ __forceinline__ void blend_forward_block(int blk, float4* s_rec, int 
           need[k] = __ballot(pw[k] >= b01.y);
           any |= need[k];
         }
-        if (any == 0ull) { if (STATS && j0 + jj < n) st_culled += 1; continue; }
+        if (any == 0ull) { if (STATS && j0 + jj < n) { st_culled += 1; st_inloop += 1; } continue; }
         if (STATS) {
           uint64_t lanes = 0ull;
 #pragma unroll
           for (int k = 0; k < PXL; ++k) { lanes |= need[k]; st_pixels += (uint32_t)__popcll(need[k]); }
           st_lanes += (uint32_t)__popcll(lanes);
         }
-        const float2 b23 = lds_read2(grp + jj * 3 + 1, 2);                                                            // opacity, r
-        const float4 c = lds_read4(grp + jj * 3 + 2);                                                                 // g, b, contributor
+        const float2 b23 = make_float2(b4.z, b4.w);                                                                   // opacity, r
         const uint32_t contributor = __float_as_uint(c.z);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
@@ -391,6 +401,7 @@ all_done:
     atomicAdd(stats + 2, (unsigned long long)st_lanes);
     atomicAdd(stats + 3, (unsigned long long)st_pixels);
     atomicAdd(stats + 4, (unsigned long long)(g.hi - g.lo));
+    atomicAdd(stats + 5, (unsigned long long)st_inloop);
   }
   if (!row_in) return;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -887,11 +898,15 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
       uint32_t ga = (uint32_t)(uintptr_t)(lds_cf4*)(s_rec + j0 * 3);   // see blend_forward_kernel
       asm volatile("" : "+v"(ga));
       lds_cf4* grp = (lds_cf4*)(uintptr_t)ga;
-      float4 a_nx = lds_read4(grp + 7 * 3), b_nx = lds_read4(grp + 7 * 3 + 1);
+      // (all twelve words one record ahead, inside the group: see the forward)
+      float4 a_nx = lds_read4(grp + 7 * 3), b_nx = lds_read4(grp + 7 * 3 + 1), c_nx = lds_read4(grp + 7 * 3 + 2);
 #pragma unroll
       for (int jj = 7; jj >= 0; --jj) {
-        const float4 a = a_nx, b = b_nx;
-        if (jj > 0) { a_nx = lds_read4(grp + (jj - 1) * 3); b_nx = lds_read4(grp + (jj - 1) * 3 + 1); }
+        const float4 a = a_nx, b = b_nx, c4 = c_nx;
+        asm volatile("" : : "v"(c4.w));   // (keeps the unused twelfth word's VGPR from being handed out while the load is in flight)
+        if (jj > 0) {
+          a_nx = lds_read4(grp + (jj - 1) * 3); b_nx = lds_read4(grp + (jj - 1) * 3 + 1); c_nx = lds_read4(grp + (jj - 1) * 3 + 2);
+        }
         const float dy = a.y - pyf;
         const float nBdy = a.w * dy, hCdy2 = (b.x * dy) * dy;
         const uint32_t pos0 = __float_as_uint(b.w);
@@ -899,8 +914,7 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
         const float pw = __builtin_fmaf(__builtin_fmaf(a.z, dx, nBdy), dx, hCdy2);
         const uint64_t need = __ballot(pos0 < lastn) & __ballot(pw >= b.y);
         if (need == 0ull) continue;
-        const float2 c = lds_read2(grp + jj * 3 + 2, 0);             // g, b
-        const float col[3] = {lds_read2(grp + jj * 3 + 2, 2).x, c.x, c.y};
+        const float col[3] = {c4.z, c4.x, c4.y};                     // r | g, b
         float s[8], sop;                                             // colour r g b | conic A B C | mean sums x y ; opacity
         const uint64_t live = bwd_update<EXP_MODE>(st, pw, dx, dy, need, b.z, col, s, sop);
         if (live != 0ull) {   // wave-uniform: somebody in this wave saw the Gaussian
@@ -930,8 +944,9 @@ int ggd_launch_blend(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, const g
   const int em = ctx->opt[GGD_OPT_EXP_MODE] == 3 ? 1 : ctx->opt[GGD_OPT_EXP_MODE];   // 3 (default): bare v_exp_f32 in the forward
   const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
   const int T = gx * gy;
+  static const int lds_pad = getenv("GGD_BLEND_LDS_PAD") ? atoi(getenv("GGD_BLEND_LDS_PAD")) : 0;   // experiment: caps the waves per CU
 #define GGD_LAUNCH_FWD2(EM, CU, ST)                                                                                     \
-  hipLaunchKernelGGL((blend_forward_kernel<EM, CU, 1, 8, ST>), dim3(4 * T), dim3(64), 0, s, prm.width, prm.height,      \
+  hipLaunchKernelGGL((blend_forward_kernel<EM, CU, 1, 8, ST>), dim3(4 * T), dim3(64), lds_pad, s, prm.width, prm.height, \
                      gx, T, splat, list, ranges, capacity, prm.bg, out_color, final_T, n_contrib, ctx->blend_stats)
 #define GGD_LAUNCH_FWD(EM, CU)                                                                                          \
   do {                                                                                                                  \
@@ -963,9 +978,10 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
   // tile form below (with 4 waves per SIMD the kernel is one wave's serial chain long, and the quarter form's wave flushes
   // its sums alone: 500 k / 512^2 184 vs 206 us)
   if (split == 1) split = T >= 2048 ? 4 : 3;
+  static const int lds_pad = getenv("GGD_BLEND_BWD_LDS_PAD") ? atoi(getenv("GGD_BLEND_BWD_LDS_PAD")) : 0;   // experiment
   if (split == 4) {
 #define GGD_LAUNCH_BQ(EM, CU)                                                                                             \
-    hipLaunchKernelGGL((blend_backward_quarter_kernel<EM, CU>), dim3(4 * T), dim3(64), 0, s, prm.width, prm.height, gx,   \
+    hipLaunchKernelGGL((blend_backward_quarter_kernel<EM, CU>), dim3(4 * T), dim3(64), lds_pad, s, prm.width, prm.height, gx, \
                        gy, splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc)
     if (cull) {
       if (em == 0) GGD_LAUNCH_BQ(0, true); else if (em == 1) GGD_LAUNCH_BQ(1, true); else GGD_LAUNCH_BQ(2, true);

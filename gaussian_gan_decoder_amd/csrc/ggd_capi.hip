@@ -175,7 +175,7 @@ extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
 extern "C" int ggd_blend_stats(ggd_ctx* ctx, int enable, unsigned long long* out) {
   if (!ctx) return GGD_E_INVALID;
   GGD_HIP(hipDeviceSynchronize());
-  if (out && ctx->blend_stats) GGD_HIP(hipMemcpy(out, ctx->stats_buf, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (out && ctx->blend_stats) GGD_HIP(hipMemcpy(out, ctx->stats_buf, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   if (enable) {
     const size_t bytes = (GGD_STATS_HEAD + 3ull * GGD_STATS_MAX_WAVES) * sizeof(unsigned long long);
     if (!ctx->stats_buf) GGD_HIP(hipMalloc((void**)&ctx->stats_buf, bytes));

@@ -66,7 +66,7 @@ struct ggd_ctx {
   size_t dbg_cap = 0;
   int opt[GGD_OPT_COUNT] = {3, 1, 1, 1, 1};  // exp: bare v_exp_f32 in the forward blend, compensated 2^x (1-2 ulp) in the backward
   unsigned long long* blend_stats = nullptr;  // debug: device counters filled by the forward blend when non-null
-  unsigned long long* stats_buf = nullptr;    // its storage: [0..4] counters, [GGD_STATS_MODE] 1 = per-wave timeline, slots from GGD_STATS_HEAD
+  unsigned long long* stats_buf = nullptr;    // its storage: [0..5] counters, [GGD_STATS_MODE] 1 = per-wave timeline, slots from GGD_STATS_HEAD
   bool profiling = false;
   hipEvent_t ev[2 * ST_COUNT] = {};
   bool ev_used[ST_COUNT] = {};

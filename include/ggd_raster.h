@@ -235,8 +235,9 @@ enum {
 };
 int ggd_set_option(ggd_ctx* ctx, int option, int value);
 /* Debug: blend work counters of the NEXT forward calls: out[0]=records visited, [1]=records culled by the wave-level
- * test, [2]=lanes with a candidate pixel (summed over visited records), [3]=candidate pixels, [4]=sum of list lengths.
- * enable=1 starts (and zeroes) counting, enable=0 stops; out (host, 5 x uint64) may be NULL.
+ * test, [2]=lanes with a candidate pixel (summed over visited records), [3]=candidate pixels, [4]=sum of list lengths,
+ * [5]=the part of [1] that was staged and then rejected by the whole wave inside the blend loop.
+ * enable=1 starts (and zeroes) counting, enable=0 stops; out (host, 6 x uint64) may be NULL.
  * enable=2 records, instead of the counters, a per-wave timeline of the next forward blend: ggd_blend_timeline copies, for
  * the first `waves` workgroups of that launch, 3 x uint64 each: start and end on the device's 100 MHz constant clock, and
  * (list length << 32 | list entries gathered before the wave's pixels were all finished).  (The counters are same-address
