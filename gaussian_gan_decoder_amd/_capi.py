@@ -43,8 +43,8 @@ class ImgView(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("ranges", "final_T", "n_contrib", "total")]
 
 
-OPT_EXP_MODE, OPT_BLEND_CULL, OPT_BINNING, OPT_BLEND_SPLIT, OPT_FOLD = 0, 1, 2, 3, 4
-STAT_FLAT_STREAK, STAT_SORT_RERUNS = 100, 101   # read-only, through get_option
+OPT_EXP_MODE, OPT_BLEND_CULL, OPT_BINNING, OPT_BLEND_SPLIT, OPT_FOLD, OPT_MSD_SORT = 0, 1, 2, 3, 4, 5
+STAT_FLAT_STREAK, STAT_SORT_RERUNS, STAT_MSD_FRAMES = 100, 101, 102   # read-only, through get_option
 SPLAT_BYTES = 48
 SPLAT_FIELDS = ("x", "y", "hA", "nB", "hC", "thr", "opacity", "r", "g", "b", "ex", "ey")
 

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
         if (pg.spec_flat && pg.flat_flag) *pg.flat_flag = 1u;
         if (pg.d_total) pg.d_total[2] = (uint32_t)flat;
         if (pg.h_tagged)   // one 64-bit store: the host sees tag, flag and total together
-          __hip_atomic_store(pg.h_tagged, ((unsigned long long)flat << 63) | ((unsigned long long)(pg.tag & 0x7fffffffu) << 32) | tv.x,
+          __hip_atomic_store(pg.h_tagged, ((unsigned long long)flat << 63) | ((unsigned long long)(pg.tag & 0x3fffffffu) << 32) | tv.x,
                              __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
@@ -439,6 +439,281 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------- two-launch depth sort (msd) ---
+// See ggd_common.h (GGD_MSD_*).  Launch 1: a tile partitions its own 4096 keys by bits 14..23 -- the ranking of a onesweep
+// pass with 1024 digits, but nothing is published and nobody is waited for: the tile's keys go, in digit order, to the tile's
+// own region of (keys_out, vals_out), and table[tile][digit] = (first slot inside the tile << 16 | count).
+constexpr int MSD_ITEMS = 16;                       // 4096 keys per tile, as the onesweep passes
+constexpr int MSD_TILE = RS_THREADS * MSD_ITEMS;
+
+// the workgroup appended to launch 1: step 2 of the offsets scan (as in the onesweep form), the sum of the histogram replicas
+// (nobody else reads them during this launch: the totals go to replica 0, where launch 2 reads its bucket bases), and the
+// verdict on the speculation: top byte constant and no bucket above GGD_MSD_CAP
+__device__ __forceinline__ void msd_piggy_block(const ggd_scan_piggy& pg, uint32_t* lds) {
+  const uint2 tv = scan_info_block(pg.wg_info, pg.n_info, pg.block_sums, pg.n_valid, pg.d_total, pg.h_total, lds);
+  uint32_t acc[5] = {0u, 0u, 0u, 0u, 0u};
+#pragma unroll 4
+  for (int r = 0; r < GGD_FOLD_REPS; ++r) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) acc[q] += pg.fold_hist[r * GGD_FOLD_REP_STRIDE + q * 256 + threadIdx.x];
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) pg.fold_hist[q * 256 + threadIdx.x] = acc[q];
+  const int flat = __syncthreads_or(acc[4] == tv.y);   // (also: nothing kept)
+  const int big = __syncthreads_or(acc[0] > (uint32_t)GGD_MSD_CAP || acc[1] > (uint32_t)GGD_MSD_CAP ||
+                                   acc[2] > (uint32_t)GGD_MSD_CAP || acc[3] > (uint32_t)GGD_MSD_CAP);
+  const unsigned long long ok = (flat && !big) ? 1ull : 0ull;
+  if (threadIdx.x == 0) {
+    if (pg.d_total) pg.d_total[2] = (uint32_t)(flat ? 1u : 0u) | ((uint32_t)ok << 1);
+    if (pg.h_tagged)
+      __hip_atomic_store(pg.h_tagged, ((unsigned long long)(flat ? 1 : 0) << 63) | (ok << 62) |
+                                      ((unsigned long long)(pg.tag & 0x3fffffffu) << 32) | tv.x,
+                         __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void sort_msd_partition_kernel(const uint32_t* __restrict__ keys_in,
+                                                                        uint32_t* __restrict__ keys_out,
+                                                                        uint32_t* __restrict__ vals_out, int64_t n,
+                                                                        uint32_t* __restrict__ table, int ntiles,
+                                                                        ggd_scan_piggy pg) {
+  __shared__ uint32_t s_cnt[4][GGD_MSD_BINS];
+  __shared__ uint32_t s_keys[MSD_TILE];
+  __shared__ uint32_t s_vals[MSD_TILE];
+  __shared__ uint32_t s_scan[4];
+  if ((int)blockIdx.x >= ntiles) { msd_piggy_block(pg, &s_cnt[0][0]); return; }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t tile = blockIdx.x;
+  const int64_t wbase = (int64_t)tile * MSD_TILE + (int64_t)wv * (64 * MSD_ITEMS);
+  uint32_t key[MSD_ITEMS], rank[MSD_ITEMS];
+#pragma unroll
+  for (int r = 0; r < MSD_ITEMS; ++r) {
+    const int64_t idx = wbase + r * 64 + lane;
+    key[r] = idx < n ? keys_in[idx] : 0xffffffffu;    // (0xFFFFFFFF = culled: dropped here, as in the onesweep form's pass 0)
+  }
+  for (int b = threadIdx.x; b < 4 * GGD_MSD_BINS; b += RS_THREADS) (&s_cnt[0][0])[b] = 0;
+  __syncthreads();
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < MSD_ITEMS; ++r) {
+    const bool ok = key[r] != 0xffffffffu;
+    const uint32_t d = (key[r] >> GGD_MSD_SHIFT) & (GGD_MSD_BINS - 1);
+    uint64_t peers = __ballot(ok);
+#pragma unroll
+    for (int b = 0; b < 10; ++b) {
+      const uint64_t m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const uint32_t before = s_cnt[wv][d];
+    const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
+    rank[r] = before + below;
+    __builtin_amdgcn_wave_barrier();
+    if (ok && below == 0) s_cnt[wv][d] = before + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  uint32_t ltot;
+  {
+    // thread t owns digits 4 t .. 4 t + 3
+    uint4 c[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) c[w] = *reinterpret_cast<const uint4*>(&s_cnt[w][4 * threadIdx.x]);
+    const uint32_t l0 = c[0].x + c[1].x + c[2].x + c[3].x, l1 = c[0].y + c[1].y + c[2].y + c[3].y;
+    const uint32_t l2 = c[0].z + c[1].z + c[2].z + c[3].z, l3 = c[0].w + c[1].w + c[2].w + c[3].w;
+    const uint32_t e0 = block_exclusive_scan_256(l0 + l1 + l2 + l3, &ltot, s_scan);   // contains __syncthreads
+    const uint32_t e1 = e0 + l0, e2 = e1 + l1, e3 = e2 + l2;
+    *reinterpret_cast<uint4*>(&s_cnt[0][4 * threadIdx.x]) = make_uint4(e0, e1, e2, e3);
+    *reinterpret_cast<uint4*>(&s_cnt[1][4 * threadIdx.x]) = make_uint4(e0 + c[0].x, e1 + c[0].y, e2 + c[0].z, e3 + c[0].w);
+    *reinterpret_cast<uint4*>(&s_cnt[2][4 * threadIdx.x]) =
+        make_uint4(e0 + c[0].x + c[1].x, e1 + c[0].y + c[1].y, e2 + c[0].z + c[1].z, e3 + c[0].w + c[1].w);
+    *reinterpret_cast<uint4*>(&s_cnt[3][4 * threadIdx.x]) =
+        make_uint4(e0 + c[0].x + c[1].x + c[2].x, e1 + c[0].y + c[1].y + c[2].y, e2 + c[0].z + c[1].z + c[2].z,
+                   e3 + c[0].w + c[1].w + c[2].w);
+    *reinterpret_cast<uint4*>(table + (size_t)tile * GGD_MSD_BINS + 4 * threadIdx.x) =
+        make_uint4((e0 << 16) | l0, (e1 << 16) | l1, (e2 << 16) | l2, (e3 << 16) | l3);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < MSD_ITEMS; ++r) {
+    if (key[r] != 0xffffffffu) {
+      const uint32_t d = (key[r] >> GGD_MSD_SHIFT) & (GGD_MSD_BINS - 1);
+      const uint32_t p = s_cnt[wv][d] + rank[r];
+      s_keys[p] = key[r];
+      s_vals[p] = (uint32_t)(wbase + r * 64 + lane);
+    }
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < ltot; p += RS_THREADS) {
+    keys_out[(size_t)tile * MSD_TILE + p] = s_keys[p];
+    vals_out[(size_t)tile * MSD_TILE + p] = s_vals[p];
+  }
+}
+
+// Launch 2: workgroup b owns bucket b (keys whose bits 14..23 equal b; bits 24..31 are the same for all keys).  Its elements
+// sit in up to `ntiles` pieces, one per tile, each already in index order; taken in tile order they are in index order
+// throughout, so two stable counting passes over bits 0..7 and 8..15 (bits 14, 15 are constant inside a bucket) leave them in
+// the order of a stable sort of the whole key.  1024 threads, <= 12 elements each, all in registers between the passes.
+constexpr int MSDF_THREADS = 1024, MSDF_ITEMS = GGD_MSD_CAP / MSDF_THREADS, MSDF_WAVES = MSDF_THREADS / 64;
+static_assert(MSDF_ITEMS * MSDF_THREADS == GGD_MSD_CAP, "bucket capacity must be a multiple of the workgroup size");
+
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* total, uint32_t* lds16) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t inc = wave_inclusive_scan(v);
+  if (lane == 63) lds16[wv] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < MSDF_WAVES; ++w) {
+    const uint32_t s = lds16[w];
+    if (w < wv) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(MSDF_THREADS) void sort_msd_finish_kernel(const uint32_t* __restrict__ keys_in,
+                                                                       const uint32_t* __restrict__ vals_in,
+                                                                       uint32_t* __restrict__ keys_out,
+                                                                       uint32_t* __restrict__ vals_out,
+                                                                       const uint32_t* __restrict__ hist /* [1024] totals */,
+                                                                       const uint32_t* __restrict__ table, int ntiles) {
+  __shared__ uint32_t s_keys[GGD_MSD_CAP];
+  __shared__ uint32_t s_vals[GGD_MSD_CAP];
+  __shared__ uint32_t s_cnt[MSDF_WAVES][RS_BINS];
+  __shared__ uint32_t s_pe[GGD_MSD_MAX_TILES];        // table entry of (tile, this bucket)
+  __shared__ uint32_t s_pd[GGD_MSD_MAX_TILES];        // first position of the tile's piece inside the bucket
+  __shared__ uint32_t s_part[MSDF_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t b = blockIdx.x;
+  const uint32_t nb = hist[b];
+  if (nb == 0u) return;
+  uint32_t base;
+  {
+    uint32_t tot;
+    const uint32_t h = hist[tid];
+    block_exclusive_scan_1024((uint32_t)tid < b ? h : 0u, &tot, s_part);
+    base = tot;
+  }
+  {
+    uint32_t carry = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += MSDF_THREADS) {
+      const int t = t0 + tid;
+      const uint32_t e = t < ntiles ? table[(size_t)t * GGD_MSD_BINS + b] : 0u;
+      uint32_t tot;
+      const uint32_t ex = block_exclusive_scan_1024(e & 0xffffu, &tot, s_part);
+      if (t < ntiles) { s_pe[t] = e; s_pd[t] = carry + ex; }
+      carry += tot;
+    }
+  }
+  __syncthreads();
+  auto piece_of = [&](uint32_t p) {   // the largest tile whose piece starts at or before p (not empty: the next one starts behind p)
+    int lo = 0;
+#pragma unroll
+    for (int step = GGD_MSD_MAX_TILES / 2; step >= 1; step >>= 1) {
+      const int probe = lo + step;
+      if (probe < ntiles && s_pd[probe] <= p) lo = probe;
+    }
+    return lo;
+  };
+  if (nb > (uint32_t)GGD_MSD_CAP) {
+    // more keys than the workgroup holds: the frame's histogram check has already failed and the host renders the frame again --
+    // but the kernels behind this one still run, so they must find a valid permutation: the pieces, gathered in tile order
+    for (uint32_t p = tid; p < nb; p += MSDF_THREADS) {
+      const int lo = piece_of(p);
+      const size_t src = (size_t)lo * MSD_TILE + (s_pe[lo] >> 16) + (p - s_pd[lo]);
+      keys_out[(size_t)base + p] = keys_in[src];
+      vals_out[(size_t)base + p] = vals_in[src];
+    }
+    return;
+  }
+  // element p of the bucket belongs to (wave, round, lane) = (p / (64 rounds), (p / 64) % rounds, p % 64), rounds = ceil(nb / 1024):
+  // every wave owns a contiguous run of the bucket (stable ranking: earlier waves, then earlier rounds, then lower lanes) and
+  // all sixteen waves share the work of a small bucket (a fixed 12 rounds per wave left a typical 1400-key bucket to two waves)
+  uint32_t key[MSDF_ITEMS], val[MSDF_ITEMS], rank[MSDF_ITEMS];
+  const int rounds = (int)((nb + MSDF_THREADS - 1) / MSDF_THREADS);
+  const uint32_t pbase = (uint32_t)wv * (64u * (uint32_t)rounds) + (uint32_t)lane;
+#pragma unroll
+  for (int r = 0; r < MSDF_ITEMS; ++r) {
+    if (r >= rounds) break;
+    const uint32_t p = pbase + r * 64;
+    key[r] = 0u; val[r] = 0u;
+    if (p < nb) {
+      const int lo = piece_of(p);
+      const size_t src = (size_t)lo * MSD_TILE + (s_pe[lo] >> 16) + (p - s_pd[lo]);
+      key[r] = keys_in[src];
+      val[r] = vals_in[src];
+    }
+  }
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int shift = 8 * pass;
+    if (pass == 1) {
+#pragma unroll
+      for (int r = 0; r < MSDF_ITEMS; ++r) {
+        if (r >= rounds) break;
+        const uint32_t p = pbase + r * 64;
+        if (p < nb) { key[r] = s_keys[p]; val[r] = s_vals[p]; }
+      }
+    }
+    for (int z = tid; z < MSDF_WAVES * RS_BINS; z += MSDF_THREADS) (&s_cnt[0][0])[z] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MSDF_ITEMS; ++r) {
+      if (r >= rounds) break;
+      const bool ok = pbase + r * 64 < nb;
+      const uint32_t d = (key[r] >> shift) & 0xffu;
+      uint64_t peers = __ballot(ok);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const uint64_t m = __ballot((d >> bit) & 1u);
+        peers &= ((d >> bit) & 1u) ? m : ~m;
+      }
+      const uint32_t before = s_cnt[wv][d];
+      const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
+      rank[r] = before + below;
+      __builtin_amdgcn_wave_barrier();
+      if (ok && below == 0) s_cnt[wv][d] = before + (uint32_t)__popcll(peers);
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+      // thread d < 256 owns digit d: its first slot = digits below + the same digit in earlier waves (the sixteen per-wave
+      // counts are read twice rather than held: sixteen live registers per thread spilled)
+      uint32_t local = 0;
+      if (tid < RS_BINS) {
+#pragma unroll
+        for (int w = 0; w < MSDF_WAVES; ++w) local += s_cnt[w][tid];
+      }
+      uint32_t tot;
+      uint32_t run = block_exclusive_scan_1024(tid < RS_BINS ? local : 0u, &tot, s_part);
+      if (tid < RS_BINS) {
+#pragma unroll
+        for (int w = 0; w < MSDF_WAVES; ++w) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MSDF_ITEMS; ++r) {
+      if (r >= rounds) break;
+      if (pbase + r * 64 < nb) {
+        const uint32_t d = (key[r] >> shift) & 0xffu;
+        const uint32_t p = s_cnt[wv][d] + rank[r];
+        s_keys[p] = key[r];
+        s_vals[p] = val[r];
+      }
+    }
+    __syncthreads();
+  }
+  for (uint32_t p = tid; p < nb; p += MSDF_THREADS) {
+    keys_out[(size_t)base + p] = s_keys[p];
+    vals_out[(size_t)base + p] = s_vals[p];
+  }
+}
+
 // ------------------------------------------------------------------------------------------- tile ranges -----
 __global__ __launch_bounds__(256) void ranges_kernel(const uint64_t* __restrict__ keys, int64_t n,
                                                      uint32_t* __restrict__ ranges) {
@@ -609,6 +884,33 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
                          (flag_flat_last && p == passes - 1) ? tickets + RS_MAX_PASSES + 1 : nullptr, 1);
     kin = kout; vin = vout;
   }
+  GGD_HIP(hipGetLastError());
+  return GGD_OK;
+}
+
+
+size_t ggd_sort32_msd_table_bytes(int64_t n) {
+  const int64_t ntiles = (n + MSD_TILE - 1) / MSD_TILE;
+  return ggd_align((size_t)(ntiles > 0 ? ntiles : 1) * GGD_MSD_BINS * sizeof(uint32_t));
+}
+bool ggd_sort32_msd_supported(int64_t n) { return n > 0 && (n + MSD_TILE - 1) / MSD_TILE <= GGD_MSD_MAX_TILES; }
+
+// The two-launch form of ggd_launch_sort32_iota (folded front end built with fold.msd; the scan's step 2 rides on launch 1 as
+// before, its step 3 is left to the caller's binning launch): result in (keys_a, vals_a); the consumers' "flat" word stays 0.
+int ggd_launch_sort32_msd(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
+                          uint32_t* keys_b, uint32_t* vals_b, int64_t n, uint32_t* table, const ggd_scan_piggy* piggy,
+                          const ggd_fold* fold) {
+  if (n <= 0) return GGD_OK;
+  if (!fold || !fold->msd || !piggy || !piggy->wg_info || !ggd_sort32_msd_supported(n))
+    return ggd_fail(ctx, GGD_E_INVALID, "sort32 (two launches): needs the folded front end in its msd form");
+  const int ntiles = (int)((n + MSD_TILE - 1) / MSD_TILE);
+  uint32_t* tickets = fold->ctl + GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE;
+  ggd_scan_piggy pg = *piggy;
+  pg.n_valid = tickets + RS_MAX_PASSES; pg.fold_hist = fold->ctl; pg.msd = 1;
+  hipLaunchKernelGGL(sort_msd_partition_kernel, dim3(ntiles + 1), dim3(RS_THREADS), 0, s, keys_src, keys_b, vals_b, n, table,
+                     ntiles, pg);
+  hipLaunchKernelGGL(sort_msd_finish_kernel, dim3(GGD_MSD_BINS), dim3(MSDF_THREADS), 0, s, keys_b, vals_b, keys_a, vals_a,
+                     fold->ctl, table, ntiles);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }

@@ -113,6 +113,7 @@ extern "C" ggd_ctx* ggd_create(int device) {
   if (const char* e = getenv("GGD_BLEND_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= 4) ctx->opt[GGD_OPT_BLEND_SPLIT] = v; }
   if (const char* e = getenv("GGD_BLEND_CULL")) ctx->opt[GGD_OPT_BLEND_CULL] = atoi(e) != 0;
   if (const char* e = getenv("GGD_FOLD")) ctx->opt[GGD_OPT_FOLD] = atoi(e) != 0;
+  if (const char* e = getenv("GGD_MSD_SORT")) ctx->opt[GGD_OPT_MSD_SORT] = atoi(e) != 0;
   int prev = 0;
   (void)hipGetDevice(&prev);
   bool ok = hipSetDevice(device) == hipSuccess &&
@@ -166,7 +167,7 @@ extern "C" const char* ggd_last_error(ggd_ctx* ctx) { return ctx ? ctx->err.c_st
 
 extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
   if (!ctx) return GGD_E_INVALID;
-  static const int kMax[GGD_OPT_COUNT] = {3, 1, 3, 4, 1};
+  static const int kMax[GGD_OPT_COUNT] = {3, 1, 3, 4, 1, 1};
   if (option < 0 || option >= GGD_OPT_COUNT || value < 0 || value > kMax[option])
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_set_option: unknown option or value");
   ctx->opt[option] = value;
@@ -201,6 +202,7 @@ extern "C" int ggd_blend_timeline(ggd_ctx* ctx, unsigned long long* out, int wav
 extern "C" int ggd_get_option(ggd_ctx* ctx, int option) {
   if (ctx && option == GGD_STAT_FLAT_STREAK) return ctx->flat_streak;
   if (ctx && option == GGD_STAT_SORT_RERUNS) return (int)(ctx->spec3_misses & 0x7fffffffull);
+  if (ctx && option == GGD_STAT_MSD_FRAMES) return (int)(ctx->msd_frames & 0x7fffffffull);
   if (!ctx || option < 0 || option >= GGD_OPT_COUNT) return GGD_E_INVALID;
   return ctx->opt[option];
 }
@@ -293,6 +295,7 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
   const bool ride = defer_scan && ctx->h_words_dev;
   ggd_fold fold;
   ctx->fold_active = false;
+  ctx->msd_frame = false;
   if (ride && ctx->opt[GGD_OPT_FOLD] != 0) {
     const int nwg = (prm->P + 255) / 256;
     if (ctx->scan_sums_cap < 3 * nwg + 64) {   // [exclusive prefixes: nwg words | {sum, kept}: nwg uint2]
@@ -329,6 +332,11 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
     fold.clear_words = (uint32_t)ctx->foldctl_dirty[oth];
     fold.wg_info = reinterpret_cast<uint2*>(ctx->scan_sums + (((size_t)nwg + 1) & ~(size_t)1));
     fold.rows = ((prm->width + 15) / 16 <= 64 && (prm->height + 15) / 16 <= 64) ? 1 : 0;
+    // two-launch depth sort: speculated under the conditions of the three-pass form (render_enqueue: folded, tile binning,
+    // speculative, a streak of flat frames), decided HERE because it selects the histograms this launch builds
+    ctx->msd_frame = ctx->opt[GGD_OPT_MSD_SORT] != 0 && ctx->opt[GGD_OPT_FOLD] == 1 && ctx->flat_streak >= GGD_FLAT_STREAK &&
+                     ctx->msd_ban == 0 && ggd_sort32_msd_supported(prm->P);
+    fold.msd = ctx->msd_frame ? 1 : 0;
     ctx->foldctl_dirty[oth] = 0;       // (clean once this launch has run)
     ctx->foldctl_dirty[cur] = need;    // what this frame may write
     ctx->fold_cur = oth;
@@ -386,18 +394,19 @@ static int geometry_finish(ggd_ctx* ctx, void* stream, const ggd_params* prm, in
     // call's tag (an event record behind that launch would cost the GPU a ~6 us bubble between two kernels).  Every few
     // thousand polls the stream is queried: if it has drained without the tag (a failed launch), fall back to the copy.
     volatile unsigned long long* slot = reinterpret_cast<volatile unsigned long long*>(ctx->h_words + 2);
-    const unsigned long long want = ctx->r_tag;   // (31 bits; bit 63 of the word: this frame's top depth digit is constant)
+    const unsigned long long want = ctx->r_tag;   // (30 bits; bit 63 of the word: this frame's top depth digit is constant,
+                                                  // bit 62: the two-launch sort's histograms say it was valid for this frame)
     unsigned long long v = *slot;
-    for (unsigned spins = 0; ((v >> 32) & 0x7fffffffull) != want; ++spins) {
+    for (unsigned spins = 0; ((v >> 32) & 0x3fffffffull) != want; ++spins) {
       __builtin_ia32_pause();
       if ((spins & 0xfff) == 0xfff) {
         const hipError_t q = hipStreamQuery(static_cast<hipStream_t>(stream));
         if (q == hipSuccess) {
           v = *slot;
-          if (((v >> 32) & 0x7fffffffull) != want) {
+          if (((v >> 32) & 0x3fffffffull) != want) {
             uint32_t w3[3] = {0u, 0u, 0u};
             GGD_HIP(hipMemcpy(w3, ctx->d_words, sizeof(w3), hipMemcpyDeviceToHost));
-            v = ((unsigned long long)(w3[2] & 1u) << 63) | (want << 32) | w3[0];
+            v = ((unsigned long long)(w3[2] & 1u) << 63) | ((unsigned long long)((w3[2] >> 1) & 1u) << 62) | (want << 32) | w3[0];
           }
           break;
         }
@@ -408,6 +417,7 @@ static int geometry_finish(ggd_ctx* ctx, void* stream, const ggd_params* prm, in
     }
     ctx->h_words[0] = (uint32_t)v;
     ctx->frame_flat = (v >> 63) != 0ull;
+    ctx->frame_msd_ok = ((v >> 62) & 1ull) != 0ull;
   } else {
     GGD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   }
@@ -474,7 +484,8 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
     const size_t pairs = ggd_align((size_t)prm->P * sizeof(uint32_t));
     const size_t sort_tmp = ggd_sort32_tmp_bytes(prm->P);
     const size_t bin_tmp = ggd_rowbin_tmp_bytes(prm->P, capacity, prm->width, prm->height);
-    rc = ggd_reserve_scratch(ctx, 4 * pairs + sort_tmp + bin_tmp, s);
+    const size_t msd_tab = (ctx->msd_frame && ctx->scan_deferred && ctx->fold_active) ? ggd_sort32_msd_table_bytes(prm->P) : 0;
+    rc = ggd_reserve_scratch(ctx, 4 * pairs + sort_tmp + bin_tmp + msd_tab, s);
     if (rc != GGD_OK) return rc;
     char* sc = static_cast<char*>(ctx->scratch);
     uint32_t* ka = reinterpret_cast<uint32_t*>(sc);
@@ -502,7 +513,7 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
         pg.n = prm->P; pg.nb = ggd_scan_blocks(prm->P); pg.block_sums = ctx->scan_sums;
         pg.d_total = ctx->d_words; pg.h_total = ctx->h_words_dev;
         pg.h_tagged = reinterpret_cast<unsigned long long*>(ctx->h_words_dev + 2);
-        ctx->r_tag = (ctx->r_tag + 1u) & 0x7fffffffu;
+        ctx->r_tag = (ctx->r_tag + 1u) & 0x3fffffffu;
         if (ctx->r_tag == 0u) ctx->r_tag = 1u;
         pg.tag = ctx->r_tag;
         if (folded) {
@@ -519,6 +530,14 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
       // launched; ggd_forward re-renders a frame for which that was wrong (frame_flat arrives with num_rendered)
       ctx->frame_folded = folded;
       ctx->spec3 = folded && rowbin && speculative && ctx->flat_streak >= GGD_FLAT_STREAK && ctx->opt[GGD_OPT_FOLD] == 1;
+      const bool msd = folded && ctx->msd_frame;   // (this call's preprocess built the two-launch sort's histograms)
+      if (msd && !ctx->spec3) return ggd_fail(ctx, GGD_E_INVALID, "internal: two-launch sort outside the speculative tile-binning path");
+      if (!msd) ctx->msd_frame = false;
+      fold.msd = msd ? 1 : 0;
+      if (msd)
+        rc = ggd_launch_sort32_msd(ctx, s, depth_keys, ka, va, kb, vb, prm->P,
+                                   reinterpret_cast<uint32_t*>(sc + 4 * pairs + sort_tmp + bin_tmp), &pg, &fold);
+      else
       rc = ggd_launch_sort32_iota(ctx, s, depth_keys, ka, va, kb, vb, prm->P, 32, tmp, sort_tmp, folded ? nullptr : clean_ctl,
                                   riding ? &pg : nullptr, rowbin, !rowbin, folded ? &fold : nullptr, ctx->spec3);
       ctx->r_pending = riding && rc == GGD_OK;
@@ -605,7 +624,7 @@ static int forward_spec_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* pr
   int rc = geometry_enqueue(ctx, stream, prm, means3D, shs, colors_precomp, opacities, scales, rotations,
                             cov3D_precomp, geom_buf, radii, num_rendered, true);
   if (rc != GGD_OK) return rc;
-  ctx->spec3 = false; ctx->frame_folded = false; ctx->frame_flat = false;
+  ctx->spec3 = false; ctx->frame_folded = false; ctx->frame_flat = false; ctx->frame_msd_ok = false;
   return render_enqueue(ctx, stream, prm, geom_buf, capacity, capacity, binning_buf, img_buf, out_color, true);
 }
 // ... and the collection of num_rendered (+ "the depth keys' top byte was constant") once the launch that delivers it has run;
@@ -614,12 +633,16 @@ static int forward_spec_collect(ggd_ctx* ctx, void* stream, const ggd_params* pr
                                 int64_t capacity, void* img_buf, float* out_color, int64_t* num_rendered) {
   int rc = geometry_finish(ctx, stream, prm, num_rendered);
   if (rc != GGD_OK) return rc;
-  const bool spec3 = ctx->spec3;
-  ctx->spec3 = false;
+  const bool spec3 = ctx->spec3, msd = ctx->msd_frame;
+  ctx->spec3 = false; ctx->msd_frame = false;
   if (ctx->frame_folded) ctx->flat_streak = ctx->frame_flat ? (ctx->flat_streak < (1 << 30) ? ctx->flat_streak + 1 : ctx->flat_streak) : 0;
+  if (ctx->frame_folded && ctx->msd_ban > 0) ctx->msd_ban -= 1;
+  const bool msd_missed = msd && !(ctx->frame_flat && ctx->frame_msd_ok);
+  if (msd_missed) ctx->msd_ban = GGD_MSD_BAN;   // (a bucket above the finish kernel's capacity, or a varying top byte)
+  if (msd && !msd_missed) ctx->msd_frames += 1;
   if (*num_rendered > capacity)
     return ggd_fail(ctx, GGD_E_CAPACITY, "binning_buf capacity is below num_rendered: re-run with a larger buffer");
-  if (spec3 && !ctx->frame_flat) {   // three sort passes were not enough for this frame: bin and blend it again, in full
+  if (msd_missed || (spec3 && !ctx->frame_flat)) {   // the short form of the sort did not hold for this frame: bin and blend it again, in full
     ctx->spec3_misses += 1;
     return render_enqueue(ctx, stream, prm, geom_buf, capacity, *num_rendered, binning_buf, img_buf, out_color, false);
   }

@@ -54,6 +54,11 @@ struct ggd_ctx {
   bool frame_flat = false;          // this call's top byte was constant (read with num_rendered)
   bool frame_folded = false;        // ... and it ran the folded front end (frame_flat is meaningful)
   unsigned long long spec3_misses = 0;
+  // two-launch sort (GGD_OPT_MSD_SORT): decided per frame before the preprocess launch (it selects the histograms to build)
+  bool msd_frame = false;           // this call's front end built the two-launch sort's histograms
+  bool frame_msd_ok = false;        // ... and they say the two-launch sort was valid for this frame (read with num_rendered)
+  int msd_ban = 0;                  // frames to wait before speculating again after a frame it was not valid for
+  unsigned long long msd_frames = 0;
   // ggd_forward_enqueue ... ggd_forward_collect: the frame whose num_rendered has not been collected yet
   struct { bool valid = false; ggd_params prm; const void* geom = nullptr; void* binning = nullptr; int64_t capacity = 0;
            void* img = nullptr; float* out = nullptr; } pending;
@@ -64,7 +69,7 @@ struct ggd_ctx {
   void* dbg_keys = nullptr;     // debug copy of the unsorted list
   void* dbg_vals = nullptr;
   size_t dbg_cap = 0;
-  int opt[GGD_OPT_COUNT] = {3, 1, 1, 1, 1};  // exp: bare v_exp_f32 in the forward blend, compensated 2^x (1-2 ulp) in the backward
+  int opt[GGD_OPT_COUNT] = {3, 1, 1, 1, 1, 1};  // exp: bare v_exp_f32 in the forward blend, compensated 2^x (1-2 ulp) in the backward
   unsigned long long* blend_stats = nullptr;  // debug: device counters filled by the forward blend when non-null
   unsigned long long* stats_buf = nullptr;    // its storage: [0..5] counters, [GGD_STATS_MODE] 1 = per-wave timeline, slots from GGD_STATS_HEAD
   bool profiling = false;
@@ -97,6 +102,7 @@ struct ggd_scan_piggy {
   int spec_flat = 0;                        // != 0: only three passes were launched -- set *flat_flag whatever the histogram says
   uint32_t* fold_hist = nullptr;            // the folded front end's histogram replicas: the workgroup that runs step 2 also adds
                                             // replicas 1 .. REPS-1 of passes 1 .. 3 into replica 0 (only pass 0 reads them all)
+  int msd = 0;                              // two-launch sort: fold_hist holds [1024 | 256] bins per replica, all summed into replica 0
 };
 
 // The depth sort's histogram kernel folded into the preprocess kernel (single-call forward on the tile-binning path): every
@@ -107,7 +113,19 @@ struct ggd_scan_piggy {
 // to 64 | status words of the 4 passes]; two blocks alternate, each cleared by the preprocess of the frame before its use.
 constexpr int GGD_FOLD_REPS = 16;   // (32 / 16 / 8 replicas: 4114 / 4140 / 4150 frames per second at 1 M / 1024^2; 3907 workgroups over 8 would
                                     // keep one address busy 80 % of the kernel's time, 16 leaves a margin)
-constexpr int GGD_FOLD_REP_STRIDE = 4 * 256;
+constexpr int GGD_FOLD_REP_STRIDE = 5 * 256;   // ordinary frames: the four byte histograms [p * 256 + digit], 256 spare words;
+                                               // two-launch sort (below): [1024 bins of key bits 14..23 | 256 bins of the top byte]
+// Two-launch depth sort (round 5; `msd` in ggd_fold / ggd_scan_piggy): when the keys' top byte is constant -- the precondition of
+// the three-pass speculation -- the 24 varying bits are ordered by ONE most-significant-digit partition and an in-LDS finish
+// instead of three onesweep passes with their cross-tile look-back (48 -> see DESIGN.md):
+//   launch 1  every 4096-key tile partitions ITS OWN keys by bits 14..23 (1024 buckets, stable, culled keys dropped), writes
+//             them to its own region and a table {offset, count} per (tile, bucket) -- no dependency between tiles at all;
+//   launch 2  one 1024-thread workgroup per bucket gathers the bucket's pieces from all tiles in tile order (= index order),
+//             orders them by bits 0..13 with two stable counting passes in LDS and writes the run to its final place (bucket
+//             bases = prefix of the preprocess kernel's 1024-bin histogram).
+// The host speculates (after GGD_FLAT_STREAK flat frames); the frame's own histograms verify (top byte constant, no bucket above
+// GGD_MSD_CAP) and a frame that fails is binned and blended again by the ordinary path (as for the skipped fourth pass).
+constexpr int GGD_MSD_SHIFT = 14, GGD_MSD_BINS = 1024, GGD_MSD_CAP = 12288, GGD_MSD_MAX_TILES = 2048, GGD_MSD_BAN = 64;
 constexpr int GGD_FOLD_ROWTOT = GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE + 64;   // REPS x 64 words: entries per tile ROW (grids of <= 64
                                                                            // rows), for the row binning's first level
 constexpr int GGD_FOLD_HEAD = GGD_FOLD_ROWTOT + GGD_FOLD_REPS * 64;        // words in front of the status words
@@ -117,6 +135,7 @@ struct ggd_fold {
   uint32_t clear_words = 0;       // ... and how much of it the preprocess clears for the next frame
   uint2* wg_info = nullptr;       // [ceil(P / 256)]
   int rows = 0;                   // != 0: also count the Gaussians per tile row (the grid has <= 64 rows)
+  int msd = 0;                    // != 0: histograms of the two-launch sort (key bits 14..23, top byte) instead of the four bytes
 };
 // control block: [head | sort status words of the 4 passes | level-1 binning status words]
 size_t ggd_fold_ctl_words(int64_t P);
@@ -197,6 +216,11 @@ int ggd_launch_sort32_iota(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src
 //       set regardless, so that they read the third pass's output (a valid permutation either way)
 constexpr int GGD_FLAT_STREAK = 8;
 const uint32_t* ggd_sort32_flat_ptr(const void* ctl);
+size_t ggd_sort32_msd_table_bytes(int64_t n);
+bool ggd_sort32_msd_supported(int64_t n);
+int ggd_launch_sort32_msd(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src, uint32_t* keys_a, uint32_t* vals_a,
+                          uint32_t* keys_b, uint32_t* vals_b, int64_t n, uint32_t* table, const ggd_scan_piggy* piggy,
+                          const ggd_fold* fold);
 const uint32_t* ggd_fold_nvalid_ptr(const uint32_t* fold_ctl);   // the same two words of a folded front end's control block
 const uint32_t* ggd_fold_flat_ptr(const uint32_t* fold_ctl);
 // Tile binning (GGD_OPT_BINNING = 1): sorted Gaussian order -> per-tile lists + ranges.

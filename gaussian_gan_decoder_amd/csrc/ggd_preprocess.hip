@@ -29,12 +29,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     uint8_t* __restrict__ clamped, int32_t* __restrict__ radii, uint32_t* __restrict__ depth_keys,
     uint2* __restrict__ rect, uint32_t* __restrict__ trap_flag, uint32_t* __restrict__ zero_ptr, int zero_words,
     ggd_fold fold) {
-  __shared__ uint32_t s_hist[FOLD ? 4 * 256 : 1];
+  __shared__ uint32_t s_hist[FOLD ? GGD_FOLD_REP_STRIDE : 1];
   __shared__ uint32_t s_red[FOLD ? 8 : 1];
   __shared__ int s_rowdiff[FOLD ? 65 : 1];
   if constexpr (FOLD) {
     for (uint32_t z = blockIdx.x * 256 + threadIdx.x; z < fold.clear_words; z += gridDim.x * 256) fold.clear[z] = 0u;
-    for (int b = threadIdx.x; b < 4 * 256; b += 256) s_hist[b] = 0u;
+    for (int b = threadIdx.x; b < GGD_FOLD_REP_STRIDE; b += 256) s_hist[b] = 0u;
     if (threadIdx.x < 65) s_rowdiff[threadIdx.x] = 0;
     __syncthreads();
   } else {
@@ -190,6 +190,16 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
       // (as sort_global_hist_kernel: the two high bytes -- sign / exponent / leading mantissa bits of a depth -- are usually
       // shared by the whole wave: one lane adds the count instead of 64 conflicting LDS atomics)
       const int leader = __builtin_ctzll(act);
+      if (fold.msd) {   // two-launch sort: bits 14..23 (never shared by a wave) and the top byte (almost always)
+        if (visible) atomicAdd(&s_hist[(key >> GGD_MSD_SHIFT) & (GGD_MSD_BINS - 1)], 1u);
+        const uint32_t d = key >> 24;
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
+        if (__ballot(visible && d != d0) == 0ull) {
+          if (lane == leader) atomicAdd(&s_hist[GGD_MSD_BINS + d0], (uint32_t)__popcll(act));
+        } else if (visible) {
+          atomicAdd(&s_hist[GGD_MSD_BINS + d], 1u);
+        }
+      } else
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         const uint32_t d = (key >> (8 * pass)) & 0xffu;
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     if (lane == 0) { s_red[wv] = tsum; s_red[4 + wv] = (uint32_t)__popcll(act); }
     __syncthreads();
     uint32_t* hist = fold.ctl + (blockIdx.x % GGD_FOLD_REPS) * GGD_FOLD_REP_STRIDE;
-    for (int b = threadIdx.x; b < 4 * 256; b += 256) {
+    for (int b = threadIdx.x; b < GGD_FOLD_REP_STRIDE; b += 256) {
       const uint32_t c = s_hist[b];
       if (c) atomicAdd(&hist[b], c);
     }

@@ -231,6 +231,11 @@ enum {
   GGD_OPT_FOLD = 4,       /* single-call forward on the tile-binning path: 1 (default) = the per-Gaussian kernel also builds the
                              depth sort's digit histograms and the first step of the offsets scan (no histogram launch);
                              0 = separate histogram launch.  Results are identical. */
+  GGD_OPT_MSD_SORT = 5,   /* 1 (default): once the depth keys' top byte has been constant for 8 frames, the depth sort of the
+                             single-call forward runs as TWO launches (one partition by key bits 14..23 without any dependency
+                             between tiles + an in-LDS finish per bucket) instead of three onesweep passes; verified by every
+                             frame's own histograms, a frame it does not hold for is re-rendered by the ordinary path.
+                             0 = never.  Results are identical. */
   GGD_OPT_COUNT
 };
 int ggd_set_option(ggd_ctx* ctx, int option, int value);
@@ -251,7 +256,8 @@ int ggd_get_option(ggd_ctx* ctx, int option);
  * ggd_forward returns (results are identical either way). */
 enum {
   GGD_STAT_FLAT_STREAK = 100,   /* consecutive frames whose top depth digit was constant */
-  GGD_STAT_SORT_RERUNS = 101    /* frames re-rendered because three sort passes were not enough */
+  GGD_STAT_SORT_RERUNS = 101,   /* frames re-rendered because the speculated short form of the depth sort did not hold */
+  GGD_STAT_MSD_FRAMES = 102     /* frames whose depth sort ran as two launches (GGD_OPT_MSD_SORT) */
 };
 
 /*

@@ -411,6 +411,57 @@ def test_fourth_sort_pass_is_skipped_after_a_streak_and_a_wrong_guess_is_rendere
     assert ctx.get_option(_capi.STAT_FLAT_STREAK) == 1
 
 
+def test_depth_sort_in_two_launches_after_a_streak_is_exact_and_an_oversized_bucket_is_rendered_again(native_lib):
+    """GGD_OPT_MSD_SORT: after 8 flat single-call frames the depth sort runs as one most-significant-digit partition + an
+    in-LDS finish per bucket (GGD_STAT_MSD_FRAMES counts them).  Lists and ranges must stay bit-identical to the oracle's --
+    on a scene of several sort tiles with exact depth ties (duplicates keep their index order), on a tiny scene, and when the
+    scenes alternate.  A scene that puts more keys into one bucket (equal key bits 14..23) than the finish kernel holds in LDS
+    fails the frame's own histogram check: the frame is rendered again by the ordinary path and the speculation pauses."""
+    from gaussian_gan_decoder_amd import _capi
+    ctx = _capi.context_for(torch.device("cuda:0"))
+    big = scene_inputs(P=70000, size=256, lsm=-5.0, seed=41)
+    m = big["means3D"].clone(); m[1000:3000] = m[40000:42000]                   # exact depth ties across sort tiles
+    big["means3D"] = m.contiguous()
+    tiny = scene_inputs(P=700, size=256, lsm=-3.5, seed=42)
+    # 60 000 Gaussians on a plane facing the camera (about 22 000 on screen): their depths share bits 14..23 -> one bucket > 12 288
+    slab = scene_inputs(P=60000, size=256, lsm=-5.5, seed=43)
+    view = slab["viewmatrix"]
+    fwd, cam_pos = view[:3, 2], torch.inverse(view)[3, :3]
+    rel = slab["means3D"] - cam_pos
+    slab["means3D"] = (slab["means3D"] - (rel @ fwd - 2.7)[:, None] * fwd[None, :] * (1.0 - 1e-5)).contiguous()
+    o = {k: run_oracle(d) for k, d in (("big", big), ("tiny", tiny), ("slab", slab))}
+    dk = o["slab"]["depths"][o["slab"]["radii"] > 0].astype(np.float32).view(np.uint32)
+    assert np.bincount((dk >> 14) & 1023).max() > 12288 and len(np.unique(dk >> 24)) == 1     # the premise
+    d_of = dict(big=big, tiny=tiny, slab=slab)
+
+    def check(k):
+        n = run_native(d_of[k], debug=False)
+        assert n["num_rendered"] == o[k]["num_rendered"]
+        np.testing.assert_array_equal(n["point_list"], o[k]["point_list"])
+        np.testing.assert_array_equal(n["ranges"], o[k]["ranges"])
+        assert np.abs(n["color"].cpu().numpy() - o[k]["color"]).max() <= 1e-5
+    for k in ("big", "tiny", "slab"):
+        check(k)                                                    # two-call form first (capacity hints)
+    ctx.set_option(_capi.OPT_MSD_SORT, 1)
+    m0, r0 = ctx.get_option(_capi.STAT_MSD_FRAMES), ctx.get_option(_capi.STAT_SORT_RERUNS)
+    for _ in range(100):                                           # (an earlier test's pause of the speculation may still run)
+        check("big")
+        if ctx.get_option(_capi.STAT_MSD_FRAMES) > m0:
+            break
+    m0 = ctx.get_option(_capi.STAT_MSD_FRAMES)
+    assert m0 > 0 and ctx.get_option(_capi.STAT_SORT_RERUNS) == r0
+    for k in ("big", "tiny", "big", "big", "tiny"):
+        check(k)
+    assert ctx.get_option(_capi.STAT_MSD_FRAMES) == m0 + 5 and ctx.get_option(_capi.STAT_SORT_RERUNS) == r0
+    check("slab")                                                   # one bucket too large: verified on the device, rendered again
+    assert ctx.get_option(_capi.STAT_SORT_RERUNS) == r0 + 1 and ctx.get_option(_capi.STAT_MSD_FRAMES) == m0 + 5
+    check("big")                                                    # the speculation pauses (three passes) ...
+    assert ctx.get_option(_capi.STAT_MSD_FRAMES) == m0 + 5 and ctx.get_option(_capi.STAT_SORT_RERUNS) == r0 + 1
+    ctx.set_option(_capi.OPT_MSD_SORT, 0)
+    check("big")
+    ctx.set_option(_capi.OPT_MSD_SORT, 1)
+
+
 @pytest.mark.parametrize("slots", [1, 2, 3])
 def test_frame_pipeline_returns_the_frames_of_the_ordinary_path(native_lib, slots):
     """FramePipeline (ggd_forward_enqueue / ggd_forward_collect: several frames in flight, num_rendered collected a round later)
