@@ -124,13 +124,12 @@ def _require_cuda(t: torch.Tensor):
                            "there is no CPU fallback")
 
 
-def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
-                               cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
-                               sh, degree, campos, prefiltered, debug, raw_attributes=False):
-    """== upstream `_C.rasterize_gaussians(...)`: returns
-    (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer).  binningBuffer may be larger than
-    num_rendered needs (single-call forward with a capacity hint); the sorted list sits at its offset 0 either way, so
-    the backward takes num_rendered as R exactly like upstream."""
+def _marshal_forward(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                     projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
+                     raw_attributes=False):
+    """Validation and marshalling of one forward call, shared by `rasterize_gaussians_native` and `FramePipeline.submit` (a
+    mis-shaped input must become a ValueError on both paths, not an out-of-bounds device read).  Returns (dev, P, the seven
+    contiguous fp32 input tensors or None, prm, keep): `keep` holds every tensor the C call reads, for as long as it may."""
     _require_cuda(means3D)
     dev = means3D.device
     if means3D.dim() != 2 or means3D.size(1) != 3:
@@ -138,12 +137,17 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
     P = means3D.size(0)
     means3D = _f32c(means3D, "means3D", dev)
     opacities = _f32c(opacities, "opacities", dev)
+    if opacities.numel() != P:
+        raise ValueError("opacities must hold one value per point")
     have = lambda t: t is not None and t.numel() > 0
     sh_c = _f32c(sh, "sh", dev) if have(sh) else None
     col_c = _f32c(colors_precomp, "colors_precomp", dev) if have(colors_precomp) else None
     sc_c = _f32c(scales, "scales", dev) if have(scales) else None
     rot_c = _f32c(rotations, "rotations", dev) if have(rotations) else None
     cov_c = _f32c(cov3D_precomp, "cov3D_precomp", dev) if have(cov3D_precomp) else None
+    for t, n, what in ((col_c, 3, "colors_precomp"), (sc_c, 3, "scales"), (rot_c, 4, "rotations"), (cov_c, 6, "cov3D_precomp")):
+        if t is not None and t.numel() != P * n:
+            raise ValueError(f"{what} must have dimensions (num_points, {n})")
     M = 0
     if sh_c is not None:
         if sh_c.dim() != 3 or sh_c.size(0) != P or sh_c.size(2) != 3:
@@ -151,8 +155,21 @@ def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, r
         M = sh_c.size(1)
     rs = GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier,
                                        viewmatrix, projmatrix, degree, campos, prefiltered, debug, raw_attributes)
-    keep: list = []
+    keep: list = [means3D, opacities, sh_c, col_c, sc_c, rot_c, cov_c]
     prm = _params(rs, P, M, dev, keep)
+    return dev, P, (means3D, opacities, sh_c, col_c, sc_c, rot_c, cov_c), prm, keep
+
+
+def rasterize_gaussians_native(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
+                               cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width,
+                               sh, degree, campos, prefiltered, debug, raw_attributes=False):
+    """== upstream `_C.rasterize_gaussians(...)`: returns
+    (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer).  binningBuffer may be larger than
+    num_rendered needs (single-call forward with a capacity hint); the sorted list sits at its offset 0 either way, so
+    the backward takes num_rendered as R exactly like upstream."""
+    dev, P, (means3D, opacities, sh_c, col_c, sc_c, rot_c, cov_c), prm, keep = _marshal_forward(
+        bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+        tanfovx, tanfovy, image_height, image_width, sh, degree, campos, prefiltered, debug, raw_attributes)
     # (the GPU idles while this wrapper runs between two frames of a render loop: sizes are cached, the stream is looked
     # up once, and the device guard is only entered when another device is current)
     ctx, stream_handle = _capi.context_and_stream(dev)
@@ -206,7 +223,11 @@ class FramePipeline:
     `rasterize_gaussians_native` plus a `torch.cuda.Event` recorded behind that frame -- make the consuming stream
     `wait_event` it (or synchronise) before reading the tensors.  `drain()` returns the results still pending, oldest first.
 
-    The slot's stream first waits for the stream that is current at `submit`, so inputs produced there are safe to use.  A
+    The slot's stream first waits for the stream that is current at `submit`, so inputs produced there are safe to use; every
+    input tensor is `record_stream`ed on the slot's stream (the frame's blend may still be reading `bg` when its num_rendered is
+    collected and the references are dropped), so per-frame temporaries are safe to pass.  The OUTPUTS are
+    allocated on the slot's stream: a consumer on another stream must `wait_event` the returned event and, if it lets go of
+    the tensors before its own work on them has finished, `record_stream` them on its stream.  A
     frame for which no capacity hint exists yet (first frame of a shape), a `debug` frame, or one whose binning overflowed
     its capacity is rendered through the ordinary synchronous path on the slot's stream; results are identical either way."""
 
@@ -223,6 +244,8 @@ class FramePipeline:
         if pend is None:
             return None
         slot["pending"] = None
+        # (the collected frame's binning / blend may still be running -- ggd_forward_collect returns with num_rendered; its inputs
+        # were record_stream'ed on this slot's stream at submit, so dropping the references here is safe)
         with torch.cuda.stream(slot["stream"]):
             if "result" in pend:                      # rendered synchronously at submit time
                 res = pend["result"]
@@ -252,37 +275,26 @@ class FramePipeline:
         slot = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
         prev = self._collect(slot)
-        _require_cuda(means3D)
-        dev = means3D.device
+        # (validation and marshalling on the CALLER's stream: a conversion to contiguous fp32 is the caller's work)
+        dev, P, (means3D_c, opac_c, sh_c, col_c, sc_c, rot_c, cov_c), prm, keep = _marshal_forward(*args)
         slot["stream"].wait_stream(torch.cuda.current_stream(dev))
+        for t in keep:                            # allocated on the caller's stream, read on the slot's: the caching allocator
+            if t is not None:                     # must not hand the block out again before the slot's work at the time of the
+                t.record_stream(slot["stream"])   # free has run (the blend reads bg long after num_rendered has been collected)
         with torch.cuda.stream(slot["stream"]):
-            P = means3D.size(0)
             H, W = int(image_height), int(image_width)
             ctx, handle = _capi.context_and_stream(dev)
             key = (P, W, H)
             hint = ctx.capacity_hint.get(key)
             if hint is None or P == 0 or debug:
                 self.synchronous_frames += 1
-                slot["pending"] = dict(result=rasterize_gaussians_native(*args))
+                slot["pending"] = dict(result=rasterize_gaussians_native(*args), keep=keep)
                 return prev
-            means3D_c = _f32c(means3D, "means3D", dev)
-            opac_c = _f32c(opacities, "opacities", dev)
-            have = lambda t: t is not None and t.numel() > 0
-            sh_c = _f32c(sh, "sh", dev) if have(sh) else None
-            col_c = _f32c(colors_precomp, "colors_precomp", dev) if have(colors_precomp) else None
-            sc_c = _f32c(scales, "scales", dev) if have(scales) else None
-            rot_c = _f32c(rotations, "rotations", dev) if have(rotations) else None
-            cov_c = _f32c(cov3D_precomp, "cov3D_precomp", dev) if have(cov3D_precomp) else None
-            M = sh_c.size(1) if sh_c is not None else 0
-            rs = GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix,
-                                               projmatrix, degree, campos, prefiltered, debug, raw_attributes)
-            keep: list = [means3D_c, opac_c, sh_c, col_c, sc_c, rot_c, cov_c]
-            prm = _params(rs, P, M, dev, keep)
             cap = _capacity(hint)
             lib = ctx.lib
             if not lib.ggd_forward_can_speculate(ctx.handle, C.byref(prm), cap):
                 self.synchronous_frames += 1
-                slot["pending"] = dict(result=rasterize_gaussians_native(*args))
+                slot["pending"] = dict(result=rasterize_gaussians_native(*args), keep=keep)
                 return prev
             u8 = dict(dtype=torch.uint8, device=dev)
             color = torch.empty((3, H, W), dtype=torch.float32, device=dev)

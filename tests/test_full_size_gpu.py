@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 import torch
 
-from _util import (scene_inputs, run_native, run_native_backward, run_oracle, backward_reference, check_gradients)
+from _util import (scene_inputs, run_native, run_native_backward, run_oracle, backward_reference, check_gradients,
+                   assert_blend_matches)
 from gaussian_gan_decoder_amd.synthetic import make_dL_dpix
 
 pytestmark = pytest.mark.gpu
@@ -122,15 +123,12 @@ def test_full_size_matches_oracle(native_lib, kind):
         np.testing.assert_array_equal(n["point_list"], o["point_list"])
         np.testing.assert_array_equal(n["ranges"], o["ranges"])
         color = n["color"].cpu().numpy()
-        same = n["n_contrib"] == o["n_contrib"]
-        flips = int((~same).sum())
-        assert flips <= (1024 * 1024) // 100000, f"{flips} n_contrib mismatches"
-        err = np.abs(color - o["color"])[:, same].max()
-        assert err <= 1e-5, f"max |dRGB| = {err}"
-        assert np.abs(n["final_T"] - o["final_T"])[same].max() <= 1e-5
+        if base is None:
+            frag, err = assert_blend_matches(n, o, what=f"{kind} path {path}")   # excluded by cause: the oracle's fragile-pixel mask
+            flips = int((n["n_contrib"] != o["n_contrib"]).sum())
         if base is None:
             base = (color, n["n_contrib"].copy())
-            print(f"  max |dRGB| = {err:.2e}, n_contrib flips = {flips}")
+            print(f"  max |dRGB| = {err:.2e} outside the {int(frag.sum())} fragile pixels, n_contrib flips (all inside) = {flips}")
         else:   # the three paths build the same lists, so the blend output is bit-identical
             np.testing.assert_array_equal(color, base[0])
             np.testing.assert_array_equal(n["n_contrib"], base[1])

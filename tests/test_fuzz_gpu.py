@@ -1,7 +1,9 @@
 """Seeded random differential test of the forward + backward raster against the oracle: image shapes that are not
 multiples of the tile (and strips wider / taller than 64 tiles), SH degrees 0-3 with more stored coefficients than active
-ones, precomputed colours / covariances, scale modifiers, every binning path and blend form, two exp modes -- the
-combinations no hand-written case lists.  120 small scenes: the whole file runs in ~10 s."""
+ones, precomputed colours / covariances, scale modifiers, every binning path and blend form, the exp modes INCLUDING the shipped
+default (3: bare v_exp_f32 forward, compensated backward), the depth sort's front end folded or not, its two-launch form on or
+off, and a third of the seeds through `FramePipeline` (ggd_forward_enqueue / _collect) -- the combinations no hand-written case
+lists.  Pixels are excluded by cause (the oracle's fragile-pixel mask), never by outcome.  120 small scenes: ~15 s."""
 import numpy as np
 import pytest
 import torch
@@ -27,8 +29,45 @@ def _case(seed):
                      sh_M=None if use_colors else M, use_colors=use_colors, use_cov=use_cov, lsm=float(rng.uniform(-6.5, -3.0)),
                      fov_deg=float(rng.uniform(6.0, 20.0)), width=W, height=H, scale_modifier=float(rng.choice([1.0, 0.7, 1.6])))
     opts = dict(binning=int(rng.choice([0, 1, 2, 3])), split=int(rng.choice([1, 3, 4])), cull=int(rng.rand() < 0.8),
-                exp_mode=int(rng.choice([0, 2])))
+                exp_mode=int(rng.choice([0, 2, 3, 3])), fold=int(rng.rand() < 0.6), msd=int(rng.rand() < 0.7),
+                pipeline=bool(seed % 3 == 2))
     return d, opts
+
+
+def _through_pipeline(d, frames, options):
+    """`frames` renderings of `d` through a 2-slot FramePipeline (the first of a shape takes the ordinary path inside it), the
+    slots' own contexts set to `options` {option: value} (and back to what they were afterwards: contexts are cached per
+    stream handle, and handles are recycled); returns the decoded outputs of every frame."""
+    from gaussian_gan_decoder_amd import rasterizer as R, _capi
+    from _util import decode_buffers
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.empty(0, device=dev) if x is None else x.to(dev)
+    args = (t(d["bg"]), t(d["means3D"]), t(d["colors_precomp"]), t(d["opacities"]), t(d["scales"]), t(d["rotations"]),
+            d["scale_modifier"], t(d["cov3D_precomp"]), t(d["viewmatrix"]), t(d["projmatrix"]), d["tanfovx"], d["tanfovy"],
+            d["H"], d["W"], t(d["shs"]), d["sh_degree"], t(d["campos"]), False, False)
+    pipe = R.FramePipeline(dev, slots=2)
+    saved = []
+    for s_ in pipe.slots:
+        with torch.cuda.stream(s_["stream"]):
+            c = _capi.context_and_stream(dev)[0]
+        saved.append((c, {k: c.get_option(k) for k in options}))
+        for k, v in options.items():
+            c.set_option(k, v)
+    try:
+        res = [r for r in (pipe.submit(*args) for _ in range(frames)) if r is not None] + pipe.drain()
+    finally:
+        torch.cuda.synchronize(dev)
+        for c, old in saved:
+            for k, v in old.items():
+                c.set_option(k, v)
+    assert len(res) == frames
+    outs = []
+    for (num_rendered, color, radii, geom, binning, img, ev) in res:
+        ev.synchronize()
+        o = dict(num_rendered=num_rendered, color=color, radii=radii, geom=geom, binning=binning, img=img)
+        o.update(decode_buffers(d["P"], d["W"], d["H"], num_rendered, geom, binning, img))
+        outs.append(o)
+    return outs
 
 
 @pytest.mark.parametrize("seed", range(120))
@@ -39,12 +78,18 @@ def test_random_configuration_matches_oracle(native_lib, seed):
     o = run_oracle(d)
     frag = fragile_pixels(o)
     cx = _capi.context_for(torch.device("cuda:0"))
-    saved = [cx.get_option(k) for k in (_capi.OPT_BLEND_SPLIT, _capi.OPT_BLEND_CULL, _capi.OPT_EXP_MODE)]
+    keys = (_capi.OPT_BLEND_SPLIT, _capi.OPT_BLEND_CULL, _capi.OPT_EXP_MODE, _capi.OPT_FOLD, _capi.OPT_MSD_SORT)
+    saved = [cx.get_option(k) for k in keys]
     try:
-        cx.set_option(_capi.OPT_BLEND_SPLIT, opts["split"]); cx.set_option(_capi.OPT_BLEND_CULL, opts["cull"])
-        cx.set_option(_capi.OPT_EXP_MODE, opts["exp_mode"])
-        for rep in range(2):      # the second call of a shape takes the single-call (capacity hint) form where it exists
-            n = run_native(d, debug=False, binning=opts["binning"])
+        for k, v in zip(keys, (opts["split"], opts["cull"], opts["exp_mode"], opts["fold"], opts["msd"])):
+            cx.set_option(k, v)
+        if opts["pipeline"]:
+            frames = _through_pipeline(d, 4, dict(zip(keys + (_capi.OPT_BINNING,), (opts["split"], opts["cull"], opts["exp_mode"],
+                                                                                   opts["fold"], opts["msd"], opts["binning"]))))
+        else:
+            frames = None
+        for rep in range(2 if frames is None else len(frames)):   # the second call of a shape takes the single-call (capacity hint) form where it exists
+            n = run_native(d, debug=False, binning=opts["binning"]) if frames is None else frames[rep]
             assert n["num_rendered"] == o["num_rendered"], (opts, W, H, P)
             np.testing.assert_array_equal(n["radii"].cpu().numpy(), o["radii"])
             np.testing.assert_array_equal(n["point_list"], o["point_list"], err_msg=str(opts))
@@ -59,6 +104,6 @@ def test_random_configuration_matches_oracle(native_lib, seed):
         nb = run_native_backward(d, n, g)
         assert check_gradients(d, nb, ref, budget, fragile) <= 1.0, opts
     finally:
-        for k, v in zip((_capi.OPT_BLEND_SPLIT, _capi.OPT_BLEND_CULL, _capi.OPT_EXP_MODE), saved):
+        for k, v in zip(keys, saved):
             cx.set_option(k, v)
         cx.set_option(_capi.OPT_BINNING, 1)

@@ -94,10 +94,11 @@ def test_backward_kernel_forms_match_oracle(native_lib, case, split):
 
 @pytest.mark.parametrize("split", [3, 4])
 @pytest.mark.parametrize("cull", [0, 1])
-@pytest.mark.parametrize("exp_mode", [0, 1, 2])
+@pytest.mark.parametrize("exp_mode", [0, 1, 2, 3])
 def test_backward_options_match_oracle(native_lib, split, cull, exp_mode):
-    """The backward blend's two production forms (tile form 3, quarter form 4) with wave-level culling on / off and the three
-    exp variants, each consistent with a forward run under the same options: all gradients inside the fp32 budget."""
+    """The backward blend's two production forms (tile form 3, quarter form 4) with wave-level culling on / off and the four
+    exp settings (3 = the shipped default: bare v_exp_f32 forward, compensated backward), each consistent with a forward run
+    under the same options: all gradients inside the fp32 budget."""
     import torch as _t
     from gaussian_gan_decoder_amd import _capi
     cx = _capi.context_for(_t.device("cuda:0"))

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import scene_inputs, run_oracle, run_native, adversarial_inputs
+from _util import scene_inputs, run_oracle, run_native, adversarial_inputs, assert_blend_matches
 
 pytestmark = pytest.mark.gpu
 
@@ -64,14 +64,8 @@ def test_forward_stages_match_oracle(native_lib, case):
     np.testing.assert_array_equal(n["ranges"], o["ranges"])
     # ---- blend
     color = n["color"].cpu().numpy()
-    err = np.abs(color - o["color"])
-    flips = int((n["n_contrib"] != o["n_contrib"]).sum())
-    # a pixel whose n_contrib differs took a different threshold branch (expf ulp); exclude those from the RGB
-    # bound, but allow at most 1 per 100k pixels
-    same = n["n_contrib"] == o["n_contrib"]
-    assert flips <= max(1, (d["W"] * d["H"]) // 100000), f"{flips} n_contrib mismatches"
-    assert err[:, same].max(initial=0.0) <= RGB_ATOL, f"max |dRGB| = {err[:, same].max()}"
-    assert np.abs(n["final_T"] - o["final_T"])[same].max(initial=0.0) <= RGB_ATOL
+    # pixels are excluded by CAUSE (the oracle's mask of decisions within 1e-6 of a threshold), not by outcome
+    assert_blend_matches(n, o, atol=RGB_ATOL)
     # ---- the production binning path (depth-sort the Gaussians + one stable tile-binning pass; debug=0) must build
     #      the very same lists / ranges as the duplicateWithKeys + radix-sort path used above (debug=1 key taps)
     n2 = run_native(d, debug=False, binning=2)
