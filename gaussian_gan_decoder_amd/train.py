@@ -81,14 +81,20 @@ class DecoderTrainer:
                  loss_fn=None, process_group=None, fused_activations: bool = False, fused_decoder: bool = False,
                  backbone_params: int = 0, perceptual_weight: float = 0.0, perceptual_width_div: int = 1,
                  scene_streams: bool = False, decoder_precision: str = "bf16", plane_axes: str = "eg3d",
-                 triplane_depth=None, fused_planes=None):
+                 triplane_depth=None, fused_planes=None, force_comm=None):
         """plane_axes / triplane_depth: the generator whose planes are decoded -- ("eg3d", None): tri-planes
         [3, C, res, res]; ("panohead", 3): PanoHead's tri-grids [3, C * 3, res, res] sampled with a 3-D grid_sample
         (the reference's default generator: main/train_pano2gaussian_decoder.py:43, PanoHead/train.py:230,318,
         sequential_decoder_reverse.py:41-50).  fused_planes (default: on for CUDA): the scenes' planes
         `planes * latent` are never materialised -- one channel-last copy of the shared planes per step, the per-scene
-        modulation applied inside the gather / scatter kernels, all scenes' plane gradients added into one buffer."""
+        modulation applied inside the gather / scatter kernels, all scenes' plane gradients added into one buffer; channel
+        counts the gather kernels do not take (not a power of two <= 64) keep the materialised-planes path.
+        force_comm (default: the environment variable GGD_FORCE_COMM): take the collective path -- hooks, async all-reduce
+        units, waits -- whenever a process group exists, even with ONE rank (exercises the RCCL communicator, work handles
+        and their stream semantics on a single GPU; the sum over one rank is the identity)."""
+        import os
         import torch.distributed as dist
+        self.force_comm = bool(int(os.environ.get("GGD_FORCE_COMM", "0"))) if force_comm is None else bool(force_comm)
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.pg = process_group
         self.device = torch.device(device)
@@ -110,7 +116,10 @@ class DecoderTrainer:
             (0.5 * torch.randn(3, plane_channels * depth, plane_res, plane_res, generator=g)).to(self.device))
         self.latents = (1.0 + 0.25 * torch.randn(n_scenes_total, plane_channels * depth, generator=g)).to(self.device)
         self.plane_channels = plane_channels
-        self.fused_planes = (self.device.type == "cuda") if fused_planes is None else bool(fused_planes)
+        gather_ok = self.device.type == "cuda" and plane_channels <= 64 and (plane_channels & (plane_channels - 1)) == 0
+        if fused_planes and not gather_ok:
+            raise ValueError("fused_planes=True needs a HIP device and a power-of-two channel count <= 64")
+        self.fused_planes = gather_ok if fused_planes is None else bool(fused_planes)
         # the rest of the backbone's gradient payload (see the module docstring): a dense gradient every step through a
         # fixed probe vector, so that its all-reduce and Adam step do real work
         self.backbone = None
@@ -184,6 +193,11 @@ class DecoderTrainer:
         return self.dist.get_world_size(self.pg) if self.dist else 1
 
     @property
+    def _comm(self):
+        """True when gradients travel through the collective path (more than one rank, or force_comm with a process group)."""
+        return bool(self.dist and (self.world > 1 or self.force_comm))
+
+    @property
     def rank(self):
         return self.dist.get_rank(self.pg) if self.dist else 0
 
@@ -216,7 +230,7 @@ class DecoderTrainer:
             self._units_of_param[id(p)] = mine
             off += n
         self._hooks = []
-        if self.dist and self.world > 1:
+        if self._comm:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._grad_ready))
         self._arm_units()
@@ -227,7 +241,16 @@ class DecoderTrainer:
         and a new collective skipped -- by the next step, and the ranks would diverge silently."""
         for u in self.units:
             if u["work"] is not None:
-                u["work"].wait()
+                # (bounded: if only THIS rank's step failed, the peers never launched the matching collectives, and an unbounded
+                # wait would sit here until the backend's own timeout instead of surfacing the error that caused it)
+                import datetime
+                try:
+                    ok = u["work"].wait(timeout=datetime.timedelta(seconds=60))
+                except TypeError:                      # (a backend whose Work.wait takes no timeout)
+                    ok = u["work"].wait()
+                if ok is False:
+                    raise RuntimeError("DecoderTrainer: an all-reduce left in flight by a failed step did not complete within "
+                                       "60 s -- the ranks have diverged (did only this rank's step fail?)")
             u["missing"], u["work"] = u["need"], None
         self._launched_bytes = 0
         self._launched_in_backward = 0
@@ -276,7 +299,7 @@ class DecoderTrainer:
         reach -- a parameter without a gradient this step -- is launched here) -> / world -> sanitise -> Adam.  Bucket k's Adam
         runs while the all-reduces of the later buckets are still in flight."""
         world = self.world
-        multi = bool(self.dist and world > 1)
+        multi = self._comm
         if multi:
             for u in self.units:
                 if u["work"] is None:

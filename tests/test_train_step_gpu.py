@@ -194,3 +194,44 @@ def test_config3_size_trains(native_lib, planes):
         rel = np.abs(curves[name] - curves["fp32"]) / np.abs(curves["fp32"])
         print(f"  max relative difference of the {name} curve from the fp32 curve: {rel.max():.3%}")
         assert rel.max() <= 0.05, (name, rel)
+
+
+def test_collective_path_on_rccl_with_one_rank(native_lib):
+    """The hook-launched all-reduce path (`force_comm`) on the RCCL backend with ONE rank on the one GPU of the box: communicator
+    initialisation, async_op work handles launched from inside the backward, their stream semantics under `_timed_wait`, the
+    bounded re-arm -- none of which gloo exercises.  The sum over one rank is the identity, so two steps must leave exactly the
+    parameters of a trainer that never saw a process group (up to the run-to-run summation order of float atomics); the payload and the share launched from the backward are checked.
+    (Not a scaling measurement: pattern of eg3d/training/training_loop.py:288-299.)"""
+    import torch.distributed as dist
+    from gaussian_gan_decoder_amd.train import make_scene_batch
+    dev = torch.device("cuda:0")
+    assert not dist.is_initialized()
+    plain = _make(dev, fused_decoder=True, fused_activations=True)
+    assert not plain._comm
+    batch = make_scene_batch([0, 1], N_POINTS, SMALL["image_size"], dev, seed=0)
+    losses_plain = [plain.step(batch) for _ in range(2)]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29731")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        tr = _make(dev, fused_decoder=True, fused_activations=True, force_comm=True)
+        assert tr._comm and tr.world == 1 and len(tr._hooks) == len(tr.params)
+        tr.measure_comm = True
+        losses = [tr.step(batch) for _ in range(2)]
+        torch.cuda.synchronize()
+        n_params = sum(p.numel() for p in tr.params)
+        assert tr.last_allreduce_bytes == 4 * n_params
+        assert tr.last_allreduce_bytes_in_backward >= 0.75 * tr.last_allreduce_bytes
+        assert tr.allreduce_exposed_ms >= 0.0
+        # (equal up to the summation order of the backward's float atomics, which differs from run to run)
+        assert np.allclose(losses, losses_plain, rtol=1e-5, atol=0.0), (losses, losses_plain)
+        assert float((_flat(tr.params) - _flat(plain.params)).abs().max()) <= 2e-5
+        # a step that fails half way leaves units in flight: the next arm waits for them (bounded) and training goes on
+        tr.flat_grad.zero_()
+        tr.local_loss(batch).backward()
+        assert any(u["work"] is not None for u in tr.units)
+        tr._arm_units()
+        assert all(u["work"] is None for u in tr.units)
+        assert np.isfinite(tr.step(batch))
+    finally:
+        dist.destroy_process_group()
