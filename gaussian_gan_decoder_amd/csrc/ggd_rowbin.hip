@@ -23,6 +23,7 @@ constexpr int RB_THREADS = 256;
 constexpr int RB_WAVES = RB_THREADS / 64;
 constexpr int RB_STAGE = 4096;                     // instances a level-2 workgroup can stage in LDS (16 KB; measured: 4096 / 6144 /
                                                    // 8192 / 12288 -> 3656 / 3640 / 3594 / 3589 frames/s: occupancy beats coverage)
+constexpr int RB_STAGE1 = 4096;                    // row entries a level-1 workgroup can stage (32 KB)
 constexpr int RB_IPL = 4;                          // items per lane (2 and 8 measured slower)
 constexpr int RB_CHUNK = RB_THREADS * RB_IPL;      // 1024 items per workgroup
 constexpr int RB_WCHUNK = 64 * RB_IPL;             // 256 items per wave
@@ -126,19 +127,6 @@ __global__ __launch_bounds__(1024) void rb_scan1_kernel(uint32_t* __restrict__ c
   }
 }
 
-// Per-wave bin counts of up to RB_WCHUNK items held RB_IPL per lane: LDS difference array + prefix over lanes.
-__device__ __forceinline__ uint32_t wave_bin_counts(int* diff /*[65], zeroed*/, const uint32_t (&iv)[RB_IPL]) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int q = 0; q < RB_IPL; ++q) {
-    const uint32_t lo = iv[q] & 0xffu, hi = iv[q] >> 8;
-    if (hi > lo) { atomicAdd(&diff[lo], 1); atomicAdd(&diff[hi], -1); }
-  }
-  __builtin_amdgcn_wave_barrier();
-  __threadfence_block();
-  return (uint32_t)wave_incl_scan_i32(diff[lane]);
-}
-
 // 64 x 64 bit-matrix transpose across the wave: lane i passes row i (bit b = M[i][b]) and gets column `lane`
 // (bit i = M[i][lane]).  Six butterfly stages (block sizes 32 .. 1): in every lane pair (l, l ^ d) the off-diagonal
 // d x d blocks are exchanged; one cross-lane move per 32-bit word and stage.
@@ -169,29 +157,52 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t row) {
   return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-// Emission of one wave's items, 64 per round (lane = item on the way in, lane = BIN on the way out): every item turns
-// its interval [lo, hi) into a 64-bit row mask, the wave transposes the 64 x 64 bit matrix, and lane b then holds the
-// mask of the round's items that cover bin b -- in item order.  It drains the mask lowest bit first (the item's payload
-// comes over with ds_bpermute), storing to consecutive positions of its bin.  ~6 drain steps per round on random data
-// instead of 64 item-serial steps.  iv = lo | hi << 8 (0 = padding item).
-template <bool TWO, typename Emit>
-__device__ __forceinline__ void wave_emit(const uint32_t (&iv)[RB_IPL], const uint32_t (&pa)[RB_IPL],
-                                          const uint32_t (&pb)[RB_IPL], int n_items, uint32_t& dst, Emit&& emit) {
+// A wave's items (RB_IPL rounds of 64, lane = item, interval [lo, hi) of bins) against its 64 bins (lane = bin), round 5 form:
+//   wave_cols   every round's 64 x 64 item / bin bit matrix, transposed: cols[q] of lane b = the items of round q that cover bin
+//               b, in item order.  Returns the lane's (= bin's) number of entries: popcount of its masks -- the counts cost
+//               nothing beyond the transposes the emission needs anyway (they used to be an LDS difference array filled with
+//               two atomics per item, 25 of rb_scatter2_kernel's 59 us on the head-like scene: same-address LDS atomics
+//               serialise).
+//   wave_emit   ITEM-parallel: the lane keeps its item and walks the bins b = lo .. hi - 1 it covers; for each it reads
+//               {mask of bin b, running destination of bin b} (one 16-byte LDS read from the wave's slab, written by the bin
+//               lanes) and stores its payload at destination + (items below it in the mask).  Steps per round = the widest
+//               item (a handful), whatever the data; the bin-parallel drain it replaces took as many steps as the fullest bin
+//               holds items -- up to 64 where a depth slice of the scene projects onto a few rows (the caps of a shell).
+__device__ __forceinline__ uint32_t wave_cols(const uint32_t (&iv)[RB_IPL], int n_items, uint64_t (&cols)[RB_IPL]) {
+  uint32_t cnt = 0;
 #pragma unroll
   for (int q = 0; q < RB_IPL; ++q) {
-    if (q * 64 >= n_items) continue;   // (no `break`: keeps the loop fully unrollable, iv / pa / pb stay in registers)
+    cols[q] = 0ull;
+    if (q * 64 >= n_items) continue;   // (no `break`: keeps the loop fully unrollable)
     const uint32_t l = iv[q] & 0xffu, h = iv[q] >> 8;
     const uint64_t below_h = h >= 64u ? ~0ull : ((1ull << h) - 1ull);
     const uint64_t row = h > l ? (below_h & ~((1ull << l) - 1ull)) : 0ull;
-    uint64_t col = wave_transpose64(row);
-    while (__ballot(col != 0ull) != 0ull) {
-      const bool act = col != 0ull;
-      const int k = act ? (__ffsll((unsigned long long)col) - 1) : 0;
-      col &= col - 1ull;
-      const uint32_t a = (uint32_t)__shfl((int)pa[q], k, 64);
-      const uint32_t b = TWO ? (uint32_t)__shfl((int)pb[q], k, 64) : 0u;
-      if (act) { emit(dst, a, b); dst += 1; }
+    cols[q] = wave_transpose64(row);
+    cnt += (uint32_t)__popcll(cols[q]);
+  }
+  return cnt;
+}
+
+template <bool TWO, typename Emit>
+__device__ __forceinline__ void wave_emit(const uint32_t (&iv)[RB_IPL], const uint32_t (&pa)[RB_IPL],
+                                          const uint32_t (&pb)[RB_IPL], const uint64_t (&cols)[RB_IPL], int n_items,
+                                          uint32_t& dst, uint4* slab /* [64], this wave's */, Emit&& emit) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int q = 0; q < RB_IPL; ++q) {
+    if (q * 64 >= n_items) continue;
+    __builtin_amdgcn_wave_barrier();                      // the previous round's reads of the slab are done (LDS is in order per wave)
+    slab[lane] = make_uint4((uint32_t)cols[q], (uint32_t)(cols[q] >> 32), dst, 0u);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t h = iv[q] >> 8;
+    for (uint32_t b = iv[q] & 0xffu; __ballot(b < h) != 0ull; ++b) {
+      const bool act = b < h;
+      const uint4 e = slab[act ? b : 0u];
+      const uint64_t m = (uint64_t)e.x | ((uint64_t)e.y << 32);
+      if (act) emit(e.z + (uint32_t)__popcll(m & lt_mask), pa[q], TWO ? pb[q] : 0u);
     }
+    dst += (uint32_t)__popcll(cols[q]);
   }
 }
 
@@ -201,14 +212,12 @@ __global__ __launch_bounds__(RB_THREADS) void rb_scatter1_kernel(const uint2* __
                                                                  const uint32_t* __restrict__ prefix1,
                                                                  const uint32_t* __restrict__ tab,
                                                                  uint2* __restrict__ ent, uint32_t ent_cap) {
-  __shared__ int diff[RB_WAVES][65];
+  __shared__ uint4 slab[RB_WAVES][64];
   __shared__ uint32_t wcnt[RB_WAVES][64];
   const uint32_t n_vis = min((uint32_t)P, *n_vis_ptr);
   const uint32_t base = (uint32_t)blockIdx.x * RB_CHUNK;
   if (base >= n_vis) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int i = tid; i < RB_WAVES * 65; i += RB_THREADS) (&diff[0][0])[i] = 0;
-  __syncthreads();
   const uint32_t wbeg = base + (uint32_t)wv * RB_WCHUNK;
   const int n_items = (int)min((uint32_t)RB_WCHUNK, n_vis > wbeg ? n_vis - wbeg : 0u);
   uint32_t iv[RB_IPL], pa[RB_IPL], pb[RB_IPL];
@@ -220,13 +229,14 @@ __global__ __launch_bounds__(RB_THREADS) void rb_scatter1_kernel(const uint2* __
     pa[q] = it.x; pb[q] = it.y & 0xffffu;
     iv[q] = it.y >> 16;   // y0 | y1 << 8
   }
-  const uint32_t mine = wave_bin_counts(diff[wv], iv);
+  uint64_t cols[RB_IPL];
+  const uint32_t mine = wave_cols(iv, n_items, cols);
   wcnt[wv][lane] = mine;
   __syncthreads();
   uint32_t dst = tab[RB_TAB_ROWSTART + lane] + prefix1[(size_t)blockIdx.x * 64 + lane];
 #pragma unroll
   for (int w = 0; w < RB_WAVES; ++w) if (w < wv) dst += wcnt[w][lane];
-  wave_emit<true>(iv, pa, pb, n_items, dst, [&](uint32_t d, uint32_t id, uint32_t xx) {
+  wave_emit<true>(iv, pa, pb, cols, n_items, dst, slab[wv], [&](uint32_t d, uint32_t id, uint32_t xx) {
     if (d < ent_cap) ent[d] = make_uint2(id, xx);
   });
 }
@@ -270,9 +280,10 @@ __global__ __launch_bounds__(RB_THREADS) void rb_level1_kernel(const uint2* __re
                                                                uint2* __restrict__ ent, uint32_t ent_cap,
                                                                const uint32_t* __restrict__ order_alt,
                                                                const uint32_t* __restrict__ use_alt) {
-  __shared__ int diff[RB_WAVES][65];
+  __shared__ uint4 slab[RB_WAVES][64];
   __shared__ uint32_t wcnt[RB_WAVES][64];
   __shared__ uint32_t s_base[64];
+  __shared__ uint2 stage[RB_STAGE1];
   if (use_alt && *use_alt != 0u) order = order_alt;   // the depth sort's last pass was the identity and copied nothing
   const uint32_t n_vis = min((uint32_t)P, *n_vis_ptr);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -296,8 +307,6 @@ __global__ __launch_bounds__(RB_THREADS) void rb_level1_kernel(const uint2* __re
   }
   const uint32_t base = (uint32_t)blockIdx.x * RB_CHUNK;
   if (base >= n_vis) return;
-  for (int i = tid; i < RB_WAVES * 65; i += RB_THREADS) (&diff[0][0])[i] = 0;
-  __syncthreads();
   const uint32_t wbeg = base + (uint32_t)wv * RB_WCHUNK;
   const int n_items = (int)min((uint32_t)RB_WCHUNK, n_vis > wbeg ? n_vis - wbeg : 0u);
   uint32_t iv[RB_IPL], pa[RB_IPL], pb[RB_IPL];
@@ -313,7 +322,8 @@ __global__ __launch_bounds__(RB_THREADS) void rb_level1_kernel(const uint2* __re
       if ((int)(x1 - x0) * (int)(y1 - y0) > 0) { pb[q] = x0 | (x1 << 8); iv[q] = y0 | (y1 << 8); }
     }
   }
-  const uint32_t mine = wave_bin_counts(diff[wv], iv);
+  uint64_t cols[RB_IPL];
+  const uint32_t mine = wave_cols(iv, n_items, cols);
   wcnt[wv][lane] = mine;
   __syncthreads();
   if (wv == 0) {
@@ -332,10 +342,34 @@ __global__ __launch_bounds__(RB_THREADS) void rb_level1_kernel(const uint2* __re
     s_base[lane] = rowstart + in_group + rb_sum_words(gw, grp);
   }
   __syncthreads();
-  uint32_t dst = s_base[lane];
+  uint32_t before = 0, rowtot_c = 0;   // lane = row: this chunk's entries of the earlier waves / of the whole chunk
 #pragma unroll
-  for (int w = 0; w < RB_WAVES; ++w) if (w < wv) dst += wcnt[w][lane];
-  wave_emit<true>(iv, pa, pb, n_items, dst, [&](uint32_t d, uint32_t id, uint32_t xx) {
+  for (int w = 0; w < RB_WAVES; ++w) { const uint32_t c = wcnt[w][lane]; if (w < wv) before += c; rowtot_c += c; }
+  // As in rb_scatter2_kernel: the chunk's entries are staged in LDS in (row, item) order and every row's run leaves as
+  // lane-consecutive 8-byte stores -- emitted directly every entry was a lone store into one of 64 row lists (the head-like
+  // scene writes 3.3 M of them).  Chunks with more entries than the buffer holds keep the direct form.
+  const uint32_t rowend = wave_incl_scan_u32(rowtot_c);          // same in every wave
+  const uint32_t total = (uint32_t)__shfl((int)rowend, 63, 64);
+  const uint32_t rowbeg = rowend - rowtot_c;
+  const uint32_t gbase = s_base[lane];
+  if (total <= (uint32_t)RB_STAGE1) {
+    uint32_t ldst = rowbeg + before;
+    wave_emit<true>(iv, pa, pb, cols, n_items, ldst, slab[wv], [&](uint32_t d, uint32_t id, uint32_t xx) { stage[d] = make_uint2(id, xx); });
+    __syncthreads();
+#pragma unroll 4
+    for (int c = wv; c < 64; c += RB_WAVES) {
+      const uint32_t n = (uint32_t)__shfl((int)rowtot_c, c, 64);
+      if (n == 0) continue;
+      const uint32_t b0 = (uint32_t)__shfl((int)rowbeg, c, 64), g = (uint32_t)__shfl((int)gbase, c, 64);
+      for (uint32_t k = lane; k < n; k += 64) {
+        const uint32_t d = g + k;
+        if (d < ent_cap) ent[d] = stage[b0 + k];
+      }
+    }
+    return;
+  }
+  uint32_t dst = gbase + before;
+  wave_emit<true>(iv, pa, pb, cols, n_items, dst, slab[wv], [&](uint32_t d, uint32_t id, uint32_t xx) {
     if (d < ent_cap) ent[d] = make_uint2(id, xx);
   });
 }
@@ -351,26 +385,47 @@ __device__ __forceinline__ bool rb_block_row(const uint32_t* __restrict__ tab, u
   row = r; chunk = blk - (uint32_t)__shfl((int)first, r, 64);
   return true;
 }
+// ... and the row's entry range with it: the block table and the row starts are requested TOGETHER (a level-2 workgroup is a
+// chain of dependent memory round trips at full occupancy -- block table -> row start -> entries -> tile starts was four of
+// them; this form makes it two: {block table, row starts}, then {entries, tile starts, chunk prefixes})
+__device__ __forceinline__ bool rb_block_row_range(const uint32_t* __restrict__ tab, uint32_t blk, uint32_t ent_cap, int& row,
+                                                   uint32_t& chunk, uint32_t& rbeg, uint32_t& rend) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t first = tab[RB_TAB_ROWBLK + lane];
+  const uint32_t total = tab[RB_TAB_ROWBLK + 64];
+  const uint32_t start = tab[RB_TAB_ROWSTART + lane];
+  const uint32_t all = tab[RB_TAB_ROWSTART + 64];
+  if (blk >= total) return false;
+  const int r = __popcll(__ballot(first <= blk)) - 1;
+  row = r; chunk = blk - (uint32_t)__shfl((int)first, r, 64);
+  rbeg = (uint32_t)__shfl((int)start, r, 64);
+  rend = min(r == 63 ? all : (uint32_t)__shfl((int)start, (r + 1) & 63, 64), ent_cap);
+  return true;
+}
 
+// (counts by an LDS difference array here: the kernel does nothing else, and four bit-matrix transposes per wave -- the form the
+// scatter kernels take their counts from, where the emission needs the transposes anyway -- cost more than the atomics:
+// measured 7.7 vs 4.8 us on the 1 M cube scene, 14.7 vs 9.0 us on the shell)
 __global__ __launch_bounds__(RB_THREADS) void rb_count2_kernel(const uint2* __restrict__ ent, uint32_t ent_cap,
                                                                const uint32_t* __restrict__ tab,
                                                                uint32_t* __restrict__ counts2) {
   __shared__ int diff[65];
-  int row; uint32_t chunk;
-  if (!rb_block_row(tab, blockIdx.x, row, chunk)) return;
+  int row; uint32_t chunk, rbeg, rend;
+  if (!rb_block_row_range(tab, blockIdx.x, ent_cap, row, chunk, rbeg, rend)) return;
   const int tid = threadIdx.x;
+  const uint32_t base = rbeg + chunk * RB_CHUNK;
+  uint32_t xs[RB_IPL];
+#pragma unroll
+  for (int q = 0; q < RB_IPL; ++q) {       // (requested before the barrier below)
+    const uint32_t i = base + (uint32_t)q * RB_THREADS + tid;
+    xs[q] = i < rend ? ent[i].y : 0u;
+  }
   if (tid < 65) diff[tid] = 0;
   __syncthreads();
-  const uint32_t rbeg = tab[RB_TAB_ROWSTART + row], rend = min(tab[RB_TAB_ROWSTART + row + 1], ent_cap);
-  const uint32_t base = rbeg + chunk * RB_CHUNK;
 #pragma unroll
   for (int q = 0; q < RB_IPL; ++q) {
-    const uint32_t i = base + (uint32_t)q * RB_THREADS + tid;
-    if (i < rend) {
-      const uint32_t xx = ent[i].y;
-      const uint32_t x0 = xx & 0xffu, x1 = (xx >> 8) & 0xffu;
-      if (x1 > x0) { atomicAdd(&diff[x0], 1); atomicAdd(&diff[x1], -1); }
-    }
+    const uint32_t x0 = xs[q] & 0xffu, x1 = (xs[q] >> 8) & 0xffu;
+    if (x1 > x0) { atomicAdd(&diff[x0], 1); atomicAdd(&diff[x1], -1); }
   }
   __syncthreads();
   if (tid < 64) counts2[(size_t)blockIdx.x * 64 + tid] = (uint32_t)wave_incl_scan_i32(diff[tid]);
@@ -433,22 +488,20 @@ __global__ __launch_bounds__(RB_THREADS) void rb_scatter2_kernel(const uint2* __
                                                                  const uint32_t* __restrict__ prefix2,
                                                                  uint32_t* __restrict__ list, uint32_t capacity,
                                                                  uint32_t main_blocks, ggd_scan_piggy pg) {
-  __shared__ int diff[RB_WAVES][65];
+  __shared__ uint4 slab[RB_WAVES][64];
   __shared__ uint32_t wcnt[RB_WAVES][64];
   __shared__ uint32_t stage[RB_STAGE];
   if (blockIdx.x >= main_blocks) {   // appended workgroups: last step of the offsets scan (see ggd_scan_piggy)
     scan_apply_block<false>(pg.in, pg.out, pg.n, pg.block_sums, (int)(blockIdx.x - main_blocks), stage, pg.sum_stride);
     return;
   }
-  int row; uint32_t chunk;
-  if (!rb_block_row(tab, blockIdx.x, row, chunk)) return;
+  int row; uint32_t chunk, rbeg, rend;
+  if (!rb_block_row_range(tab, blockIdx.x, ent_cap, row, chunk, rbeg, rend)) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int i = tid; i < RB_WAVES * 65; i += RB_THREADS) (&diff[0][0])[i] = 0;
-  __syncthreads();
-  const uint32_t rbeg = tab[RB_TAB_ROWSTART + row], rend = min(tab[RB_TAB_ROWSTART + row + 1], ent_cap);
   const uint32_t wbeg = rbeg + chunk * RB_CHUNK + (uint32_t)wv * RB_WCHUNK;
   const int n_items = (int)min((uint32_t)RB_WCHUNK, rend > wbeg ? rend - wbeg : 0u);
   uint32_t iv[RB_IPL], pa[RB_IPL], pb[RB_IPL];
+  // second (and last) round trip: the entries, the tile starts and the chunk's prefixes, all requested before anything waits
 #pragma unroll
   for (int q = 0; q < RB_IPL; ++q) {
     const int i = q * 64 + lane;
@@ -457,10 +510,11 @@ __global__ __launch_bounds__(RB_THREADS) void rb_scatter2_kernel(const uint2* __
     pa[q] = it.x; pb[q] = 0;
     iv[q] = it.y & 0xffffu;   // x0 | x1 << 8
   }
-  const uint32_t mine = wave_bin_counts(diff[wv], iv);
+  const uint32_t gbase = tab[RB_TAB_TILESTART + row * 64 + lane] + prefix2[(size_t)blockIdx.x * 64 + lane];
+  uint64_t cols[RB_IPL];
+  const uint32_t mine = wave_cols(iv, n_items, cols);
   wcnt[wv][lane] = mine;
   __syncthreads();
-  const uint32_t gbase = tab[RB_TAB_TILESTART + row * 64 + lane] + prefix2[(size_t)blockIdx.x * 64 + lane];
   uint32_t before = 0, coltot = 0;   // lane = column: instances of the earlier waves / of the whole chunk
 #pragma unroll
   for (int w = 0; w < RB_WAVES; ++w) { const uint32_t c = wcnt[w][lane]; if (w < wv) before += c; coltot += c; }
@@ -472,7 +526,7 @@ __global__ __launch_bounds__(RB_THREADS) void rb_scatter2_kernel(const uint2* __
   const uint32_t colbeg = colend - coltot;
   if (total <= (uint32_t)RB_STAGE) {
     uint32_t ldst = colbeg + before;
-    wave_emit<false>(iv, pa, pb, n_items, ldst, [&](uint32_t d, uint32_t id, uint32_t) { stage[d] = id; });
+    wave_emit<false>(iv, pa, pb, cols, n_items, ldst, slab[wv], [&](uint32_t d, uint32_t id, uint32_t) { stage[d] = id; });
     __syncthreads();
     // wave w copies columns w, w + 4, ...; the column's (base, count, destination) come from the lane that owns it
 #pragma unroll 4
@@ -488,7 +542,7 @@ __global__ __launch_bounds__(RB_THREADS) void rb_scatter2_kernel(const uint2* __
     return;
   }
   uint32_t dst = gbase + before;
-  wave_emit<false>(iv, pa, pb, n_items, dst, [&](uint32_t d, uint32_t id, uint32_t) {
+  wave_emit<false>(iv, pa, pb, cols, n_items, dst, slab[wv], [&](uint32_t d, uint32_t id, uint32_t) {
     if (d < capacity) list[d] = id;
   });
 }
