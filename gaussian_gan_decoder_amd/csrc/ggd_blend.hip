@@ -484,9 +484,25 @@ struct BwdPixel { float T, nTfin, bgdot, acc[3], gpx[3]; };
 template <int EXP_MODE>
 __device__ __forceinline__ uint64_t bwd_update(BwdPixel& st, float pw, float dx, float dy, uint64_t need, float opacity,
                                                const float (&col)[3], float (&s)[8], float& sop) {
-  const float g0 = blend_exp<EXP_MODE>(pw);
+  float g0, adec;
+  if constexpr (EXP_MODE == 3) {
+    // the default pairing (bare v_exp_f32 in the forward, compensated 2^x here): the forward's G is exactly the `e` this form
+    // starts from, so the CONTRIBUTION DECISION alpha >= 1/255 is taken on the forward's own number -- a record within a few
+    // ulp of the floor is then in or out in both passes, and the transmittance replayed by T / (1 - alpha) stays consistent
+    // with the saved final_T (decided on the accurate value, the two passes could disagree on such a record, 0.4 %
+    // on everything in front of it in that pixel) -- while the VALUES use the compensated exponential.
+    const float t = pw * 1.44269502162933349609375f;
+    float lo = __builtin_fmaf(pw, 1.44269502162933349609375f, -t);
+    lo = __builtin_fmaf(pw, 1.925963033500011e-08f, lo);
+    const float e = __builtin_amdgcn_exp2f(t);
+    adec = fminf(0.99f, e * opacity);
+    g0 = __builtin_fmaf(e, lo * 0.693147182464599609375f, e);
+  } else {
+    g0 = blend_exp<EXP_MODE>(pw);
+  }
   const float a0 = fminf(0.99f, opacity * g0);
-  const uint64_t live = need & ~__ballot(pw > 0.0f) & ~__ballot(a0 < ALPHA_FLOOR);
+  if constexpr (EXP_MODE != 3) adec = a0;
+  const uint64_t live = need & ~__ballot(pw > 0.0f) & ~__ballot(adec < ALPHA_FLOOR);
   const float G = sel_or_zero(g0, live), alpha = sel_or_zero(a0, live);
   const float om = 1.0f - alpha;
   float inv = __builtin_amdgcn_rcpf(om);
@@ -968,7 +984,7 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
                               const uint32_t* n_contrib, const float* dL_dpix, float* grad_acc) {
   const int gx = (prm.width + 15) / 16, gy = (prm.height + 15) / 16;
   if (gx * gy == 0) return GGD_OK;
-  const int em = ctx->opt[GGD_OPT_EXP_MODE] == 3 ? 2 : ctx->opt[GGD_OPT_EXP_MODE];   // 3 (default): compensated 2^x in the backward
+  const int em = ctx->opt[GGD_OPT_EXP_MODE];   // 3 (default): compensated 2^x, contribution decision on the forward's bare v_exp_f32 value
   const bool cull = ctx->opt[GGD_OPT_BLEND_CULL] != 0;
   const int T = gx * gy;
   int split = ctx->opt[GGD_OPT_BLEND_SPLIT];
@@ -984,9 +1000,9 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
     hipLaunchKernelGGL((blend_backward_quarter_kernel<EM, CU>), dim3(4 * T), dim3(64), lds_pad, s, prm.width, prm.height, gx, \
                        gy, splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc)
     if (cull) {
-      if (em == 0) GGD_LAUNCH_BQ(0, true); else if (em == 1) GGD_LAUNCH_BQ(1, true); else GGD_LAUNCH_BQ(2, true);
+      if (em == 0) GGD_LAUNCH_BQ(0, true); else if (em == 1) GGD_LAUNCH_BQ(1, true); else if (em == 2) GGD_LAUNCH_BQ(2, true); else GGD_LAUNCH_BQ(3, true);
     } else {
-      if (em == 0) GGD_LAUNCH_BQ(0, false); else if (em == 1) GGD_LAUNCH_BQ(1, false); else GGD_LAUNCH_BQ(2, false);
+      if (em == 0) GGD_LAUNCH_BQ(0, false); else if (em == 1) GGD_LAUNCH_BQ(1, false); else if (em == 2) GGD_LAUNCH_BQ(2, false); else GGD_LAUNCH_BQ(3, false);
     }
 #undef GGD_LAUNCH_BQ
     GGD_HIP(hipGetLastError());
@@ -996,9 +1012,9 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
   hipLaunchKernelGGL((blend_backward_tile_kernel<EM, CU>), dim3(T), dim3(256), 0, s, prm.width, prm.height, gx,           \
                      gy, splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc)
   if (cull) {
-    if (em == 0) GGD_LAUNCH_BT(0, true); else if (em == 1) GGD_LAUNCH_BT(1, true); else GGD_LAUNCH_BT(2, true);
+    if (em == 0) GGD_LAUNCH_BT(0, true); else if (em == 1) GGD_LAUNCH_BT(1, true); else if (em == 2) GGD_LAUNCH_BT(2, true); else GGD_LAUNCH_BT(3, true);
   } else {
-    if (em == 0) GGD_LAUNCH_BT(0, false); else if (em == 1) GGD_LAUNCH_BT(1, false); else GGD_LAUNCH_BT(2, false);
+    if (em == 0) GGD_LAUNCH_BT(0, false); else if (em == 1) GGD_LAUNCH_BT(1, false); else if (em == 2) GGD_LAUNCH_BT(2, false); else GGD_LAUNCH_BT(3, false);
   }
 #undef GGD_LAUNCH_BT
   GGD_HIP(hipGetLastError());

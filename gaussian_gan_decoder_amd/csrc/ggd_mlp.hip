@@ -123,8 +123,11 @@ typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 // cancellation, whereas Phi = 0.5 + x P(x^2) has alternating coefficients up to 13 and is off by 1.5e-2 in f16), minimax fit
 // under s(1) = 1: beyond |z| = 4 the result is z or 0 whatever |z| (scripts/gelu_f16_fit.py: fit, and the error of THIS
 // instruction sequence with its roundings over every f16 value: <= 1.54e-3 for 2 <= z < 4 -- 9.8e-4 of it is the f16 rounding
-// of the result; a bf16 result is off by 7.8e-3 there -- <= 8.8e-4 elsewhere, mean 7e-5).  A pre-activation beyond +-131008
-// becomes +-inf (the reference-precision kernels clamp; this tier does not spend two instructions per pair on it).
+// of the result; a bf16 result is off by 7.8e-3 there -- <= 8.8e-4 elsewhere, mean 7e-5).  NOT SATURATING (this tier does not
+// spend two packed instructions per pair on a clamp; the reference-precision kernels do clamp): a pre-activation z > 65504
+// gives +inf (y = z / 2 is finite up to 131008, but y + |y| is not), and z < -131008 gives NaN (y = -inf: inf - inf) where the
+// true value is 0 -- one exploding pre-activation poisons THAT POINT's attributes, no other point's
+// (tests/test_decoder_gpu.py::test_exploding_preactivation_stays_inside_its_point).
 // 11 instructions per pair, conversion included: cvt, and, min, add, 6 fma, fma.
 // Measured at 1 M points (profiles/r04/decoder_forward_f16.txt), against the packed-fp32 Phi polynomial on bf16 operands of
 // rounds 1-3: kernel 905 -> 798 us with the z-form of this polynomial (12 instructions), error of the decoded attributes

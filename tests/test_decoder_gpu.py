@@ -466,3 +466,30 @@ def test_split_attrs_on_the_gpu_matches_slicing(native_lib):
             if hi - lo != 4:
                 ref[b, :, lo:hi] = wt
     assert torch.equal(a.grad, ref)
+
+
+def test_exploding_preactivation_stays_inside_its_point(native_lib):
+    """The f16 tier's packed GELU does not saturate (csrc/ggd_mlp.hip: z > 65504 -> +inf, z < -131008 -> NaN; the
+    reference-precision tier clamps).  Pinned here: a handful of points whose plane features drive the colour head's first
+    layer far beyond the f16 range may come out non-finite in THEIR attributes, every other point equals the run without them
+    bit for bit, and the fp32 tier stays finite everywhere."""
+    from gaussian_gan_decoder_amd.fused_decoder import FusedDecoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    dec = SequentialDecoderReverse().to(dev)
+    with torch.no_grad():
+        dec.color_decoder.backbone[0].weight *= 60.0
+    N = 4096
+    feats = torch.randn(N, 32, device=dev)
+    pos = torch.rand(N, 3, device=dev) - 0.5
+    bad = torch.tensor([5, 77, 1000, 4095], device=dev)
+    hot = feats.clone()
+    hot[bad] *= 6.0e4                                        # clamped to +-65504 on load: pre-activations ~ +-1e6
+    f16, f32 = FusedDecoder(dec), FusedDecoder(dec, precision="fp32")
+    base, out, out32 = f16.decode_features(feats, pos), f16.decode_features(hot, pos), f32.decode_features(hot, pos)
+    keep = torch.ones(N, dtype=torch.bool, device=dev)
+    keep[bad] = False
+    # attrs rows: [0..2] colour, [3] opacity, [4..7] rotation, [8..10] scale, [11..13] xyz
+    assert torch.equal(base[keep, :14], out[keep, :14])      # nobody else is touched
+    assert torch.isfinite(out32[:, :14]).all()               # the reference-precision tier saturates
+    assert not torch.isfinite(out[bad, :3]).all()            # (the documented behaviour of this tier, not a promise)
