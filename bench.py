@@ -127,7 +127,7 @@ def pmc_moved_bytes(workload):
     """Sum of the measured HBM bytes (committed PMC passes, see pmc_traffic) of every forward kernel of one frame."""
     import glob
     best = None
-    for fn in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "traffic.json"))):
+    for fn in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "traffic*.json"))):
         try:
             doc = json.load(open(fn))
         except (OSError, ValueError):
@@ -156,7 +156,7 @@ def pmc_valu(workload, stage):
     """SQ_INSTS_VALU per launch of the stage's kernel from the same committed PMC pass (see pmc_traffic)."""
     import glob
     best = None
-    for fn in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "traffic.json"))):
+    for fn in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "traffic*.json"))):
         try:
             doc = json.load(open(fn))
         except (OSError, ValueError):
@@ -169,13 +169,38 @@ def pmc_valu(workload, stage):
     return best
 
 
+def pmc_source(workload, stage):
+    """The committed file pmc_traffic / pmc_valu replay their numbers from (bench.py cannot collect counters itself)."""
+    import glob
+    best = None
+    root = os.path.dirname(os.path.abspath(__file__))
+    for fn in sorted(glob.glob(os.path.join(root, "profiles", "*", "traffic*.json"))):
+        try:
+            doc = json.load(open(fn))
+        except (OSError, ValueError):
+            continue
+        if doc.get("workload") == workload and doc.get("stage_to_kernel", {}).get(stage, "") in doc.get("kernels", {}):
+            best = os.path.relpath(fn, root)
+    return best
+
+
+def roofline_entry(workload, stage, P, R, W, H, kernel_ms):
+    """One roofline object (SURVEY 8d bytes of `stage` per launch / the kernel's live hipEvent time; counter traffic and VALU
+    instruction count replayed from the committed PMC pass of the same workload, named in `replayed_from`)."""
+    b = algorithmic_bytes(stage, P, R, W, H)
+    ach = b / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": stage, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": pmc_traffic(workload, stage), "algorithmic_bytes_per_launch": b, "kernel_ms": kernel_ms,
+            "valu_wave_insts": pmc_valu(workload, stage), "replayed_from": pmc_source(workload, stage)}
+
+
 def pmc_traffic(workload, stage):
     """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     corrected as profiles/*/traffic.json states).  bench.py cannot collect counters itself; the number is the one
     measured with `rocprofv3 --pmc` on this same command (profiles/r01_final/).  None when no profile of this workload."""
     import glob
     best = None
-    for fn in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "traffic.json"))):
+    for fn in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "traffic*.json"))):
         try:
             doc = json.load(open(fn))
         except (OSError, ValueError):
@@ -199,6 +224,9 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the data-parallel train-step section")
     ap.add_argument("--no-sweep", action="store_true", help="skip the forward-fps sweep over the other synthetic configs")
     ap.add_argument("--no-decode", action="store_true", help="skip the fused decode + render section (config 3)")
+    ap.add_argument("--no-inflight", action="store_true", help="skip the several-frames-in-flight sections (profiling runs: their "
+                    "overlapped frames stretch the kernels' durations in a rocprofv3 kernel trace)")
+    ap.add_argument("--no-extra-rooflines", action="store_true", help="skip roofline_shell / roofline_backward / varying_scenes")
     ap.add_argument("--train-iters", type=int, default=8)
     ap.add_argument("--train-points", type=int, default=500_000, help="positions per scene (reference: 500 000)")
     ap.add_argument("--scenes-per-gpu", type=int, default=4)
@@ -294,7 +322,7 @@ def main():
     # ---- throughput with several frames in flight (reported BESIDE the single-stream headline, never instead of it): one HIP
     #      stream + one rasterizer context per frame slot; frame k + 1's latency-bound preprocess / depth sort / binning
     #      (about one workgroup per CU) runs under frame k's VALU-bound blend.  Images are bit-identical on every slot.
-    if rank == 0:
+    if rank == 0 and not args.no_inflight:
         fif = {}
         for nslots in (2, 4):
             streams = [torch.cuda.Stream(device=dev) for _ in range(nslots)]
@@ -339,9 +367,74 @@ def main():
     # the single-call forward's front end: histograms + scan step 1 + row counts inside the preprocess
     # kernel, the fourth sort pass not launched after a streak of frames whose top depth byte was constant (verified per frame;
     # a frame it was wrong for is binned and blended again: `sort_reruns`)
+    msd_frames = ctx.get_option(_capi.STAT_MSD_FRAMES)
     extra["forward_path"] = {"fold": ctx.get_option(_capi.OPT_FOLD), "flat_streak": ctx.get_option(_capi.STAT_FLAT_STREAK),
-                             "sort_reruns": ctx.get_option(_capi.STAT_SORT_RERUNS),
-                             "kernel_launches_per_frame": 9 if ctx.get_option(_capi.OPT_FOLD) and S <= 1024 else None}
+                             "sort_reruns": ctx.get_option(_capi.STAT_SORT_RERUNS), "two_launch_sort": ctx.get_option(_capi.OPT_MSD_SORT),
+                             "two_launch_sort_frames": msd_frames, "capacity_retries": ctx.capacity_retries,
+                             "kernel_launches_per_frame": (8 if msd_frames > 0 else 9) if ctx.get_option(_capi.OPT_FOLD) and S <= 1024 else None}
+    # ---- beside the headline (rank 0): the same shape over a cycle of DIFFERENT scenes (the train step's situation: the
+    #      capacity hint, the alternating control blocks and the streak-based sort speculation see new data every frame), the
+    #      head-like "shell" scene's dominant kernel, and the backward blend, each priced like `roofline`
+    rl_shell = rl_bwd = varying = None
+    if rank == 0 and not args.no_extra_rooflines:
+        cyc = []
+        for sd, fov in ((11, 12.0), (12, 9.0), (13, 15.0), (14, 11.0), (15, 13.5)):
+            s2 = make_scene(P, S, kind, seed=sd, fov_deg=fov).to(dev)
+            c2 = s2.cam
+            cyc.append((s2.bg, s2.xyz, empty, s2.opacities.contiguous(), s2.scales.contiguous(), s2.rotations.contiguous(), 1.0, empty,
+                        c2.world_view_transform, c2.full_proj_transform, math.tan(c2.FoVx * 0.5), math.tan(c2.FoVy * 0.5), S, S,
+                        s2.features_dc.contiguous(), 0, c2.camera_center, False, False))
+        r0, c0, m0 = ctx.get_option(_capi.STAT_SORT_RERUNS), ctx.capacity_retries, ctx.get_option(_capi.STAT_MSD_FRAMES)
+        rs = []
+        for i in range(2 * len(cyc)):
+            rs.append(R.rasterize_gaussians_native(*cyc[i % len(cyc)])[0])
+        torch.cuda.synchronize(dev)
+        nv = max(100, args.steps)
+        tv = time.perf_counter()
+        for i in range(nv):
+            R.rasterize_gaussians_native(*cyc[i % len(cyc)])
+        torch.cuda.synchronize(dev)
+        tv = time.perf_counter() - tv
+        varying = {"scenes": len(cyc), "frames": nv, "frames_per_s": nv / tv, "ms_per_frame": tv / nv * 1e3,
+                   "num_rendered": sorted(set(int(r) for r in rs)), "sort_reruns": ctx.get_option(_capi.STAT_SORT_RERUNS) - r0,
+                   "capacity_retries": ctx.capacity_retries - c0, "two_launch_sort_frames": ctx.get_option(_capi.STAT_MSD_FRAMES) - m0,
+                   "what": f"{P} Gaussians, {S}x{S}, '{kind}' scenes of 5 seeds and fields of view 9..15 degrees in turn, one stream"}
+        del cyc
+        if args.workload == "1M_1024_cube":
+            Ps, Ss, ks = WORKLOADS["1M_1024_shell"]
+            s2 = make_scene(Ps, Ss, ks, seed=0).to(dev)
+            c2 = s2.cam
+            a2 = (s2.bg, s2.xyz, empty, s2.opacities.contiguous(), s2.scales.contiguous(), s2.rotations.contiguous(), 1.0, empty,
+                  c2.world_view_transform, c2.full_proj_transform, math.tan(c2.FoVx * 0.5), math.tan(c2.FoVy * 0.5), Ss, Ss,
+                  s2.features_dc.contiguous(), 0, c2.camera_center, False, False)
+            for _ in range(10):
+                o2 = R.rasterize_gaussians_native(*a2)
+            ctx.set_profiling(True)
+            accs: dict = {}
+            for _ in range(20):
+                o2 = R.rasterize_gaussians_native(*a2)
+                for k, v in ctx.stage_times().items():
+                    accs[k] = accs.get(k, 0.0) + v / 20
+            ctx.set_profiling(False)
+            rl_shell = roofline_entry("1M_1024_shell", "blend", Ps, int(o2[0]), Ss, Ss, accs["blend"])
+            rl_shell["stage_ms"] = {k: round(v, 5) for k, v in accs.items() if k in ("preprocess", "sort", "duplicate", "blend")}
+            rl_shell["num_rendered"] = int(o2[0])
+            del s2, a2, o2
+        # backward blend of the headline workload (quarter form), hipEvent stage time
+        gb = make_dL_dpix(S).to(dev)
+        ob = step()
+        bb = (sc.bg, sc.xyz, ob[2], empty, scales, rots, 1.0, empty, cam.world_view_transform, cam.full_proj_transform, tanx, tany, gb,
+              shs, 0, cam.camera_center, ob[3], ob[0], ob[4], ob[5], False)
+        for _ in range(3):
+            R.rasterize_gaussians_backward_native(*bb)
+        ctx.set_profiling(True)
+        tbw = 0.0
+        for _ in range(10):
+            R.rasterize_gaussians_backward_native(*bb)
+            tbw += ctx.stage_times()["blend_bwd"] / 10
+        ctx.set_profiling(False)
+        rl_bwd = roofline_entry(args.workload, "blend_bwd", P, num_rendered, S, S, tbw)
+        del gb, ob, bb
     if not args.no_sweep and rank == 0:
         # the other synthetic configurations of BASELINE.json's north_star ({100k, 1M} x {512, 1024}), forward raster only,
         # 100 frames each -- reported for the table in DESIGN.md; the headline `value` is the workload above
@@ -627,12 +720,11 @@ def main():
 
     fwd_stages = ("preprocess", "scan", "duplicate", "sort", "ranges", "blend")
     dom = max(fwd_stages, key=lambda k: stage_ms.get(k, 0.0))
-    dom_bytes = algorithmic_bytes(dom, P, num_rendered, S, S)
-    dom_s = stage_ms[dom] * 1e-3
-    achieved = dom_bytes / dom_s / 1e9
     whole = sum(algorithmic_bytes(k, P, num_rendered, S, S) for k in fwd_stages)
-    path_bytes = (algorithmic_bytes("preprocess", P, num_rendered, S, S) + 4 * P + 8 * p_vis + 2 * 16 * p_vis + 8 * row_entries
-                  + 4 * num_rendered + algorithmic_bytes("blend", P, num_rendered, S, S))
+    # (depth sort: the first launch reads 4 B / Gaussian and writes 8 B / visible one; then either two onesweep passes of
+    # 16 B / visible Gaussian each or, in its two-launch form, one in-LDS finish of 16 B / visible Gaussian)
+    path_bytes = (algorithmic_bytes("preprocess", P, num_rendered, S, S) + 4 * P + 8 * p_vis + (1 if msd_frames > 0 else 2) * 16 * p_vis
+                  + 8 * row_entries + 4 * num_rendered + algorithmic_bytes("blend", P, num_rendered, S, S))
     ms_per_step = elapsed / args.steps * 1e3
     result = {
         "metric": "forward raster frames/s, 1M Gaussians @ 1024x1024" if args.workload == "1M_1024_cube"
@@ -652,12 +744,10 @@ def main():
                                "raster fp32, inputs resident in HBM", "num_rendered": num_rendered,
                    "tiles": ((S + 15) // 16) ** 2, "tile_list_length_mean": tile_lists["mean"],
                    "tile_list_length_max": tile_lists["max"], "parallelism": f"scene-parallel x{world} (no collective)"},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, dom),
-                     "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": stage_ms[dom],
-                     # the dominant kernel is VALU-bound by intensity: its wave-level VALU instruction
-                     # count from the committed PMC pass is reported beside the HBM figure
-                     "valu_wave_insts": pmc_valu(args.workload, dom)},
+        # (the dominant kernel is VALU-bound by intensity, DESIGN.md section 4: its wave-level VALU instruction count is reported
+        # beside the HBM figure; `traffic` and `valu_wave_insts` are REPLAYED from the committed PMC pass named in `replayed_from`,
+        # `kernel_ms` is this run's own hipEvent time)
+        "roofline": roofline_entry(args.workload, dom, P, num_rendered, S, S, stage_ms[dom]),
         "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
         "frame_ms_percentiles": {k: (round(v, 5) if k != "n" else v) for k, v in frame_pct.items()},
         # whole frame against HBM: `algorithmic_bytes_path` = what THIS path has to move (preprocess, which also builds the sort's
@@ -676,6 +766,12 @@ def main():
         result["whole_frame"].update({"moved_bytes_pmc": moved["bytes"], "moved_GBps": moved["bytes"] / (ms_per_step * 1e-3) / 1e9,
                                       "moved_frac_of_hbm_peak": moved["bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "moved_bytes_source": moved["source"]})
+    if rl_shell is not None:
+        result["roofline_shell"] = rl_shell
+    if rl_bwd is not None:
+        result["roofline_backward"] = rl_bwd
+    if varying is not None:
+        result["varying_scenes"] = varying
     if decode is not None:
         m = pmc_mlp()
         if m is not None:   # MFMA-side roofline entry for the fused decoder MLP (committed rocprofv3 passes)

@@ -25,7 +25,8 @@ copy_stats("bench", "kernel_stats.csv")
 copy_stats("train", "kernel_stats_train.csv")
 copy_stats("train_fp32", "kernel_stats_train_fp32.csv")
 copy_stats("hd", "kernel_stats_hd.csv")
-for f in ("bench.json", "bench_under_rocprof.json", "full_size_errors.txt", "hd_timing.txt"):
+for f in ("bench.json", "bench_under_rocprof.json", "full_size_errors.txt", "hd_timing.txt", "frame_trace_1M_1024_cube.txt",
+          "frame_trace_1M_1024_shell.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 for sub, out in (("pmc", "pmc_summary.txt"), ("pmc_shell", "pmc_summary_shell.txt"), ("pmc_mlp", "pmc_summary_mlp.txt"),
@@ -82,7 +83,8 @@ for sub, workload, out in (("pmc", "1M_1024_cube", "traffic.json"), ("pmc_shell"
            "stage_to_kernel": {"blend": next((k for k in kern if k.startswith("blend_forward")), ""), "blend_bwd": bwd_blend,
                                "preprocess": "preprocess_kernel",
                                "duplicate": next((k for k in kern if k.startswith("rb_scatter2")), ""),
-                               "sort": next((k for k in kern if k.startswith("sort_onesweep")), "")}}
+                               "sort": next((k for k in kern if k.startswith("sort_msd_finish")),
+                                            next((k for k in kern if k.startswith("sort_onesweep")), ""))}}
     json.dump(doc, open(os.path.join(dst, out), "w"), indent=1)
 
 # ---- mlp_pmc.json
@@ -98,6 +100,8 @@ if k:
            "mfma_busy_frac": (m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * gui)) if gui else None,
            "valu_insts": m.get("SQ_INSTS_VALU"),
            "note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): the fraction of SIMD cycles "
-                   "with the matrix pipe busy, from the counter pass (the kernel runs ~20 % slower under counter collection)"}
+                   "with the matrix pipe busy, from the counter pass.  kernel_us is the kernel's duration in the kernel-trace pass of "
+                   "the same script (scripts/mlp_only.py, a cold 5-iteration run), NOT the kernel the bench line times: bench.json's "
+                   "decode_render.mlp_ms is the steady-state figure (round 4: 953 us here against 608 us timed)"}
     json.dump(doc, open(os.path.join(dst, "mlp_pmc.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(dst)))
