@@ -133,6 +133,12 @@ def test_full_size_matches_oracle(native_lib, kind):
             np.testing.assert_array_equal(color, base[0])
             np.testing.assert_array_equal(n["n_contrib"], base[1])
     g = make_dL_dpix(1024)
+    # the oracle's fragile pixels get zero upstream gradient, for the HIP backward and the reference alike (as in the fuzz and
+    # configuration tests): in the default exp pairing the backward takes a record's contribution decision on the FORWARD's
+    # exponential -- consistent with the final_T it replays -- while the float64 reference decides on the oracle's; on the
+    # ~100 pixels where a record sits within 1e-6 of the alpha floor the two may differ, and 1/255 of everything in front of
+    # that record with them
+    g[:, torch.from_numpy(frag)] = 0.0
     ref, budget, fragile = backward_reference(d, o, n, g.numpy())
     nb = run_native_backward(d, n, g)
     report = []
