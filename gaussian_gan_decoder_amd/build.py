@@ -20,7 +20,7 @@ CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "libggd_raster.so")
 SOURCES = ["ggd_capi.hip", "ggd_preprocess.hip", "ggd_binning.hip", "ggd_rowbin.hip", "ggd_blend.hip", "ggd_triplane.hip", "ggd_mlp.hip", "ggd_imgloss.hip",
            "ggd_preprocess_bwd.hip", "ggd_surface.hip"]
-HEADERS = ["ggd_common.h", "ggd_math.h", "ggd_mlp_bwd.inc", "ggd_mlp_wgrad.inc", "ggd_mlp_pack.inc", "ggd_mlp_hl.inc", "ggd_mlp_gelu.inc", "ggd_scan.inc", "ggd_rowbin_wide.inc"]
+HEADERS = ["ggd_common.h", "ggd_math.h", "ggd_mlp_bwd.inc", "ggd_mlp_wgrad.inc", "ggd_mlp_pack.inc", "ggd_mlp_hl.inc", "ggd_mlp_gelu.inc", "ggd_scan.inc", "ggd_rowbin_wide.inc", "ggd_msd_finish.inc"]
 ARCH = "gfx950"
 
 

@@ -441,11 +441,10 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
 
 
 // ------------------------------------------------------------------------------- two-launch depth sort (msd) ---
+#include "ggd_msd_finish.inc"
 // See ggd_common.h (GGD_MSD_*).  Launch 1: a tile partitions its own 4096 keys by bits 14..23 -- the ranking of a onesweep
 // pass with 1024 digits, but nothing is published and nobody is waited for: the tile's keys go, in digit order, to the tile's
 // own region of (keys_out, vals_out), and table[tile][digit] = (first slot inside the tile << 16 | count).
-constexpr int MSD_ITEMS = 16;                       // 4096 keys per tile, as the onesweep passes
-constexpr int MSD_TILE = RS_THREADS * MSD_ITEMS;
 
 // the workgroup appended to launch 1: step 2 of the offsets scan (as in the onesweep form), the sum of the histogram replicas
 // (nobody else reads them during this launch: the totals go to replica 0, where launch 2 reads its bucket bases), and the
@@ -550,167 +549,38 @@ __global__ __launch_bounds__(RS_THREADS) void sort_msd_partition_kernel(const ui
   }
 }
 
-// Launch 2: workgroup b owns bucket b (keys whose bits 14..23 equal b; bits 24..31 are the same for all keys).  Its elements
-// sit in up to `ntiles` pieces, one per tile, each already in index order; taken in tile order they are in index order
-// throughout, so two stable counting passes over bits 0..7 and 8..15 (bits 14, 15 are constant inside a bucket) leave them in
-// the order of a stable sort of the whole key.  1024 threads, <= 12 elements each, all in registers between the passes.
-constexpr int MSDF_THREADS = 1024, MSDF_ITEMS = GGD_MSD_CAP / MSDF_THREADS, MSDF_WAVES = MSDF_THREADS / 64;
-static_assert(MSDF_ITEMS * MSDF_THREADS == GGD_MSD_CAP, "bucket capacity must be a multiple of the workgroup size");
-
-__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* total, uint32_t* lds16) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t inc = wave_inclusive_scan(v);
-  if (lane == 63) lds16[wv] = inc;
-  __syncthreads();
-  uint32_t base = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < MSDF_WAVES; ++w) {
-    const uint32_t s = lds16[w];
-    if (w < wv) base += s;
-    tot += s;
-  }
-  __syncthreads();
-  *total = tot;
-  return base + inc - v;
-}
-
+// Launch 2 (see ggd_msd_finish.inc): the bucket's sorted run written to its final place (bucket bases = prefix of the histogram).
 __global__ __launch_bounds__(MSDF_THREADS) void sort_msd_finish_kernel(const uint32_t* __restrict__ keys_in,
                                                                        const uint32_t* __restrict__ vals_in,
                                                                        uint32_t* __restrict__ keys_out,
                                                                        uint32_t* __restrict__ vals_out,
                                                                        const uint32_t* __restrict__ hist /* [1024] totals */,
                                                                        const uint32_t* __restrict__ table, int ntiles) {
-  __shared__ uint32_t s_keys[GGD_MSD_CAP];
-  __shared__ uint32_t s_vals[GGD_MSD_CAP];
-  __shared__ uint32_t s_cnt[MSDF_WAVES][RS_BINS];
-  __shared__ uint32_t s_pe[GGD_MSD_MAX_TILES];        // table entry of (tile, this bucket)
-  __shared__ uint32_t s_pd[GGD_MSD_MAX_TILES];        // first position of the tile's piece inside the bucket
-  __shared__ uint32_t s_part[MSDF_WAVES];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  __shared__ msd_lds L;
+  const int tid = threadIdx.x;
   const uint32_t b = blockIdx.x;
   const uint32_t nb = hist[b];
   if (nb == 0u) return;
   uint32_t base;
   {
-    uint32_t tot;
     const uint32_t h = hist[tid];
-    block_exclusive_scan_1024((uint32_t)tid < b ? h : 0u, &tot, s_part);
-    base = tot;
+    block_exclusive_scan_1024((uint32_t)tid < b ? h : 0u, &base, L.part);
   }
-  {
-    uint32_t carry = 0;
-    for (int t0 = 0; t0 < ntiles; t0 += MSDF_THREADS) {
-      const int t = t0 + tid;
-      const uint32_t e = t < ntiles ? table[(size_t)t * GGD_MSD_BINS + b] : 0u;
-      uint32_t tot;
-      const uint32_t ex = block_exclusive_scan_1024(e & 0xffffu, &tot, s_part);
-      if (t < ntiles) { s_pe[t] = e; s_pd[t] = carry + ex; }
-      carry += tot;
-    }
-  }
-  __syncthreads();
-  auto piece_of = [&](uint32_t p) {   // the largest tile whose piece starts at or before p (not empty: the next one starts behind p)
-    int lo = 0;
-#pragma unroll
-    for (int step = GGD_MSD_MAX_TILES / 2; step >= 1; step >>= 1) {
-      const int probe = lo + step;
-      if (probe < ntiles && s_pd[probe] <= p) lo = probe;
-    }
-    return lo;
-  };
+  msd_bucket_pieces(L, table, ntiles, b);
   if (nb > (uint32_t)GGD_MSD_CAP) {
     // more keys than the workgroup holds: the frame's histogram check has already failed and the host renders the frame again --
     // but the kernels behind this one still run, so they must find a valid permutation: the pieces, gathered in tile order
     for (uint32_t p = tid; p < nb; p += MSDF_THREADS) {
-      const int lo = piece_of(p);
-      const size_t src = (size_t)lo * MSD_TILE + (s_pe[lo] >> 16) + (p - s_pd[lo]);
+      const size_t src = msd_piece_src(L, ntiles, p);
       keys_out[(size_t)base + p] = keys_in[src];
       vals_out[(size_t)base + p] = vals_in[src];
     }
     return;
   }
-  // element p of the bucket belongs to (wave, round, lane) = (p / (64 rounds), (p / 64) % rounds, p % 64), rounds = ceil(nb / 1024):
-  // every wave owns a contiguous run of the bucket (stable ranking: earlier waves, then earlier rounds, then lower lanes) and
-  // all sixteen waves share the work of a small bucket (a fixed 12 rounds per wave left a typical 1400-key bucket to two waves)
-  uint32_t key[MSDF_ITEMS], val[MSDF_ITEMS], rank[MSDF_ITEMS];
-  const int rounds = (int)((nb + MSDF_THREADS - 1) / MSDF_THREADS);
-  const uint32_t pbase = (uint32_t)wv * (64u * (uint32_t)rounds) + (uint32_t)lane;
-#pragma unroll
-  for (int r = 0; r < MSDF_ITEMS; ++r) {
-    if (r >= rounds) break;
-    const uint32_t p = pbase + r * 64;
-    key[r] = 0u; val[r] = 0u;
-    if (p < nb) {
-      const int lo = piece_of(p);
-      const size_t src = (size_t)lo * MSD_TILE + (s_pe[lo] >> 16) + (p - s_pd[lo]);
-      key[r] = keys_in[src];
-      val[r] = vals_in[src];
-    }
-  }
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int shift = 8 * pass;
-    if (pass == 1) {
-#pragma unroll
-      for (int r = 0; r < MSDF_ITEMS; ++r) {
-        if (r >= rounds) break;
-        const uint32_t p = pbase + r * 64;
-        if (p < nb) { key[r] = s_keys[p]; val[r] = s_vals[p]; }
-      }
-    }
-    for (int z = tid; z < MSDF_WAVES * RS_BINS; z += MSDF_THREADS) (&s_cnt[0][0])[z] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < MSDF_ITEMS; ++r) {
-      if (r >= rounds) break;
-      const bool ok = pbase + r * 64 < nb;
-      const uint32_t d = (key[r] >> shift) & 0xffu;
-      uint64_t peers = __ballot(ok);
-#pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
-        const uint64_t m = __ballot((d >> bit) & 1u);
-        peers &= ((d >> bit) & 1u) ? m : ~m;
-      }
-      const uint32_t before = s_cnt[wv][d];
-      const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
-      rank[r] = before + below;
-      __builtin_amdgcn_wave_barrier();
-      if (ok && below == 0) s_cnt[wv][d] = before + (uint32_t)__popcll(peers);
-      __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    {
-      // thread d < 256 owns digit d: its first slot = digits below + the same digit in earlier waves (the sixteen per-wave
-      // counts are read twice rather than held: sixteen live registers per thread spilled)
-      uint32_t local = 0;
-      if (tid < RS_BINS) {
-#pragma unroll
-        for (int w = 0; w < MSDF_WAVES; ++w) local += s_cnt[w][tid];
-      }
-      uint32_t tot;
-      uint32_t run = block_exclusive_scan_1024(tid < RS_BINS ? local : 0u, &tot, s_part);
-      if (tid < RS_BINS) {
-#pragma unroll
-        for (int w = 0; w < MSDF_WAVES; ++w) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < MSDF_ITEMS; ++r) {
-      if (r >= rounds) break;
-      if (pbase + r * 64 < nb) {
-        const uint32_t d = (key[r] >> shift) & 0xffu;
-        const uint32_t p = s_cnt[wv][d] + rank[r];
-        s_keys[p] = key[r];
-        s_vals[p] = val[r];
-      }
-    }
-    __syncthreads();
-  }
+  msd_bucket_sort(L, keys_in, vals_in, ntiles, nb);
   for (uint32_t p = tid; p < nb; p += MSDF_THREADS) {
-    keys_out[(size_t)base + p] = s_keys[p];
-    vals_out[(size_t)base + p] = s_vals[p];
+    keys_out[(size_t)base + p] = L.kv[p];
+    vals_out[(size_t)base + p] = L.kv[GGD_MSD_CAP + p];
   }
 }
 
