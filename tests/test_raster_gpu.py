@@ -456,6 +456,29 @@ def test_depth_sort_in_two_launches_after_a_streak_is_exact_and_an_oversized_buc
     ctx.set_option(_capi.OPT_MSD_SORT, 1)
 
 
+@pytest.mark.parametrize("W,H,P", [(1100, 48, 6000), (40, 1090, 6000), (333, 333, 20000), (17, 33, 300), (1040, 1040, 150000)])
+def test_two_launch_sort_on_odd_and_wide_grids(native_lib, W, H, P):
+    """The two-launch depth sort under the binning forms it can meet: grids wider / taller than 64 tiles (the wide row / column
+    binning reads the sorted order the finish kernel wrote), ragged shapes, a handful of Gaussians (most of the 1024 buckets
+    empty), and a 65 x 65-tile frame of several sort tiles.  Thirteen frames each: the streak builds, the last ones run in two
+    launches (asserted), every frame's list and ranges equal the oracle's."""
+    from gaussian_gan_decoder_amd import _capi
+    ctx = _capi.context_for(torch.device("cuda:0"))
+    d = scene_inputs(P=P, size=max(W, H), seed=50 + P % 7, lsm=-4.5, width=W, height=H)
+    o = run_oracle(d)
+    m0, r0 = ctx.get_option(_capi.STAT_MSD_FRAMES), ctx.get_option(_capi.STAT_SORT_RERUNS)
+    for i in range(80):
+        n = run_native(d, debug=False)
+        assert n["num_rendered"] == o["num_rendered"], i
+        np.testing.assert_array_equal(n["point_list"], o["point_list"], err_msg=f"frame {i}")
+        np.testing.assert_array_equal(n["ranges"], o["ranges"], err_msg=f"frame {i}")
+        if ctx.get_option(_capi.STAT_MSD_FRAMES) >= m0 + 4:
+            break
+    assert ctx.get_option(_capi.STAT_MSD_FRAMES) >= m0 + 4, "the two-launch sort never ran (a pause left by an earlier test lasts 64 frames)"
+    assert ctx.get_option(_capi.STAT_SORT_RERUNS) == r0
+    assert_blend_matches(n, o)
+
+
 @pytest.mark.parametrize("slots", [1, 2, 3])
 def test_frame_pipeline_returns_the_frames_of_the_ordinary_path(native_lib, slots):
     """FramePipeline (ggd_forward_enqueue / ggd_forward_collect: several frames in flight, num_rendered collected a round later)
