@@ -21,7 +21,7 @@ using namespace ggdm;
 // keys} of its 256 points for the offsets scan -- the sort's histogram launch and the scan's first step disappear.
 template <bool SHVEC, bool FOLD>
 __global__ __launch_bounds__(256) void preprocess_kernel(
-    int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float mod, int prefiltered, int raw,
+    int P, int M, int deg, int W, int H, float tanfovx, float tanfovy, float fx, float fy, float mod, int prefiltered, int raw,
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos_p,
     const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ colors_precomp,
     const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -54,7 +54,37 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   const Mat16 V = load_mat(view);
   const Mat16 PV = load_mat(proj);
 
-  const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+  // Every per-Gaussian input is requested HERE, in one go, whatever the culling tests below decide: behind the tests (position
+  // -> depth test -> scale / rotation -> rect test -> colour -> opacity) a wave paid four dependent trips to memory and lived
+  // 10 us, 60 % of it waiting.  The price is 16 B of colour + opacity for a Gaussian whose rect turns out empty.  Inline asm,
+  // because the compiler sinks plain loads back behind the tests (their only uses); an array this call does not have is
+  // replaced by the 64-byte view matrix so that no load sits behind a branch.  The hardware completes loads in order, but
+  // stores issued earlier (the control-block clear) share the counter: one wait for everything.
+  typedef float f3v __attribute__((ext_vector_type(3)));
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  f3v p_v, s_v, c_v;
+  f4v q_v;
+  float opac_in;
+  {
+    const float* pp = means3D + 3 * (size_t)i;
+    const float* sp = cov3D_precomp ? view : scales + 3 * (size_t)i;
+    const float* qp = cov3D_precomp ? view : rotations + 4 * (size_t)i;
+    const float* cp = colors_precomp ? colors_precomp + 3 * (size_t)i : (shs ? shs + (size_t)i * M * 3 : view);   // colour, or SH band 0
+    const float* op = opacities + i;
+    asm volatile("global_load_dwordx3 %0, %5, off\n\t"
+                 "global_load_dwordx3 %1, %6, off\n\t"
+                 "global_load_dwordx4 %2, %7, off\n\t"
+                 "global_load_dwordx3 %3, %8, off\n\t"
+                 "global_load_dword %4, %9, off\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(p_v), "=&v"(s_v), "=&v"(q_v), "=&v"(c_v), "=&v"(opac_in)
+                 : "v"(pp), "v"(sp), "v"(qp), "v"(cp), "v"(op)
+                 : "memory");
+  }
+  const float p[3] = {p_v.x, p_v.y, p_v.z};
+  float s3[3] = {s_v.x, s_v.y, s_v.z};
+  float4 q = make_float4(q_v.x, q_v.y, q_v.z, q_v.w);
+  const float rgb_in[3] = {c_v.x, c_v.y, c_v.z};
   float t[3];
   t[0] = V.m[0] * p[0] + V.m[4] * p[1] + V.m[8] * p[2] + V.m[12];
   t[1] = V.m[1] * p[0] + V.m[5] * p[1] + V.m[9] * p[2] + V.m[13];
@@ -78,8 +108,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 #pragma unroll
       for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * (size_t)i + k];
     } else {
-      float s3[3] = {scales[3 * (size_t)i], scales[3 * (size_t)i + 1], scales[3 * (size_t)i + 2]};
-      float4 q = reinterpret_cast<const float4*>(rotations)[i];
       if (raw) {
         float nrm;
         s3[0] = expf(s3[0]); s3[1] = expf(s3[1]); s3[2] = expf(s3[2]);
@@ -87,7 +115,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
       }
       cov3d_from_scale_rot(s3, mod, q, c6);
     }
-    const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
     float abc[3], Tm[2][3], tcl[3];
     bool clx, cly;
     ewa_cov2d(t, fx, fy, tanfovx, tanfovy, c6, V, abc, Tm, tcl, clx, cly);
@@ -111,8 +138,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         ntiles = (uint32_t)area;
         float rgb[3];
         if (colors_precomp) {
-          rgb[0] = colors_precomp[3 * (size_t)i]; rgb[1] = colors_precomp[3 * (size_t)i + 1];
-          rgb[2] = colors_precomp[3 * (size_t)i + 2];
+          rgb[0] = rgb_in[0]; rgb[1] = rgb_in[1]; rgb[2] = rgb_in[2];
+        } else if (deg == 0) {   // band 0 only (what the decoder's renderer passes): the coefficients arrived with the rest
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float res = SH_C0 * rgb_in[c] + 0.5f;
+            if (res < 0.0f) clamp_bits |= (1u << c);
+            rgb[c] = fmaxf(res, 0.0f);
+          }
         } else {
           const float campos[3] = {campos_p[0], campos_p[1], campos_p[2]};
           if constexpr (SHVEC) {
@@ -132,7 +165,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         }
         rect_out = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16), (uint32_t)miny | ((uint32_t)maxy << 16));
         const float conA = c * det_inv, conB = -b * det_inv, conC = a * det_inv;   // the published conic
-        const float opac = raw ? act_sigmoid(opacities[i]) : opacities[i];
+        const float opac = raw ? act_sigmoid(opac_in) : opac_in;
         out.x = px; out.y = py;
         out.hA = -0.5f * conA; out.nB = -conB; out.hC = -0.5f * conC;   // exact rescalings (see ggd_raster.h)
         out.opacity = opac;
@@ -144,17 +177,20 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
         // sqrt(tau2 A / det), inflated by 1.001 + 4e-6 trace^2 / det (the fp32 rounding of the in-loop power evaluation
         // grows with the anisotropy of Q) + 0.01 px.  Indefinite / NaN conics get +inf (never culled by the box);
         // thr > 0 (opacity < 1/255) can never be reached by power <= 0: the box is empty (extents -inf).
-        const float L = logf(1.0f / (255.0f * opac));
+        // (hardware log / reciprocal / square root here, not the correctly rounded forms the bit-exact outputs above need: this
+        // block only has to be conservative, its 1-2 ulp are three orders below the margins -- 28.2 -> 25.9 us at 1 M points)
+        const float L = -__logf(255.0f * opac);
         float thr = L - (2e-5f + 1e-6f * fabsf(L));
         const float cdet = conA * conC - conB * conB;
         const float tau2 = -2.0f * thr;
         float ex = __builtin_huge_valf(), ey = __builtin_huge_valf();
         if (cdet > 0.0f) {
-          const float sdet = tau2 / cdet;
+          const float rc = __builtin_amdgcn_rcpf(cdet);
+          const float sdet = tau2 * rc;
           const float tr = conA + conC;
-          const float infl = 1.001f + 4e-6f * (tr * tr) / cdet;
-          ex = __builtin_sqrtf(fmaxf(sdet * conC, 0.0f)) * infl + 0.01f;
-          ey = __builtin_sqrtf(fmaxf(sdet * conA, 0.0f)) * infl + 0.01f;
+          const float infl = 1.001f + 4e-6f * (tr * tr) * rc;
+          ex = __builtin_amdgcn_sqrtf(fmaxf(sdet * conC, 0.0f)) * infl + 0.01f;
+          ey = __builtin_amdgcn_sqrtf(fmaxf(sdet * conA, 0.0f)) * infl + 0.01f;
         }
         if (tau2 < 0.0f) { ex = -__builtin_huge_valf(); ey = -__builtin_huge_valf(); }
         // opacity <= 0 (or NaN): L is +inf / NaN and thr = inf - inf = NaN.  alpha = opacity * G <= 0 < 1/255 for every
@@ -264,9 +300,11 @@ int ggd_launch_preprocess(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm, co
   const int grid = (prm.P + 255) / 256;
   const bool shvec = !colors_precomp && prm.M > 1 && prm.M <= 16 && ((3 * prm.M) & 3) == 0;
   const ggd_fold f = fold ? *fold : ggd_fold{};
+  // focal lengths: wave-uniform correctly rounded divisions, done once here (same fp32 expression, same result)
+  const float fx = (float)prm.width / (2.0f * prm.tanfovx), fy = (float)prm.height / (2.0f * prm.tanfovy);
 #define GGD_PREPROCESS(SHV, FLD)                                                                                            \
   hipLaunchKernelGGL((preprocess_kernel<SHV, FLD>), dim3(grid), dim3(256), 0, s, prm.P, prm.M, prm.sh_degree, prm.width,     \
-                     prm.height, prm.tanfovx, prm.tanfovy, prm.scale_modifier, prm.prefiltered, prm.raw_attributes,          \
+                     prm.height, prm.tanfovx, prm.tanfovy, fx, fy, prm.scale_modifier, prm.prefiltered, prm.raw_attributes,          \
                      prm.viewmatrix, prm.projmatrix, prm.campos, means3D, shs, colors_precomp, opacities, scales, rotations, \
                      cov3D_precomp, splat, tiles_touched, clamped, radii, depth_keys, rect, trap_flag, zero_ptr,             \
                      zero_ptr ? zero_words : 0, f)

@@ -10,6 +10,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 // per iteration: NM MFMAs on 4 independent accumulators and / or NV v_fma_f32 (or v_pk_fma_f32) on 8 independent chains
 // MODE 0: MFMA only   1: VALU only   2: odd waves MFMA, even waves VALU   3: every wave both, interleaved 1 MFMA : R VALU
+// MODE 4: like 2, but the role is taken from the wave's slot ON ITS SIMD (HW_ID.wave_id parity), and the kernel records
+//         (simd, role) of every wave so that the co-residency of one MFMA and one VALU wave per SIMD is checked, not assumed
 template <int MODE, int R, bool PK>
 __global__ __launch_bounds__(1024) void probe(float* out, int iters, float seed) {
   const int wv = threadIdx.x >> 6;
@@ -18,8 +20,12 @@ __global__ __launch_bounds__(1024) void probe(float* out, int iters, float seed)
   f4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
   float v0 = seed + threadIdx.x, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3, v4 = v0 + 4, v5 = v0 + 5, v6 = v0 + 6, v7 = v0 + 7;
   const float k = 0.999f, c = 1e-3f;
-  const bool do_m = MODE == 0 || MODE == 3 || (MODE == 2 && (wv & 1));
-  const bool do_v = MODE == 1 || MODE == 3 || (MODE == 2 && !(wv & 1));
+  unsigned hwid = 0;
+  if (MODE == 4) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+  const int slot = hwid & 15, simd = (hwid >> 4) & 3;
+  const bool do_m = MODE == 0 || MODE == 3 || (MODE == 2 && (wv & 1)) || (MODE == 4 && (slot & 1));
+  const bool do_v = MODE == 1 || MODE == 3 || (MODE == 2 && !(wv & 1)) || (MODE == 4 && !(slot & 1));
+  if (MODE == 4 && blockIdx.x == 0 && (threadIdx.x & 63) == 0) { out[512 + wv] = (float)(simd * 100 + slot * 2 + (do_m ? 1 : 0)); }
 #define MF(acc) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 #define VF4A asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" \
                           : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "v"(k), "v"(c));
@@ -73,8 +79,9 @@ static void run(const char* name, int waves_per_simd, float* d) {
   if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess) printf("launch failed: ");
   // what a SIMD was asked for per iteration
   const int mf = (MODE == 1 ? 0 : 16), vf = (MODE == 0 ? 0 : 64 * R);
-  double waves_m = MODE == 2 ? waves_per_simd / 2.0 : (MODE == 1 ? 0 : waves_per_simd);
-  double waves_v = MODE == 2 ? waves_per_simd / 2.0 : (MODE == 0 ? 0 : waves_per_simd);
+  if (MODE == 4) { float h[16]; hipMemcpy(h, d + 512, sizeof(h), hipMemcpyDeviceToHost); printf("   wave -> simd*100 + slot*2 + is_mfma:"); for (int w = 0; w < threads / 64 && w < 16; ++w) printf(" %d", (int)h[w]); printf("\n"); }
+  double waves_m = MODE == 2 || MODE == 4 ? waves_per_simd / 2.0 : (MODE == 1 ? 0 : waves_per_simd);
+  double waves_v = MODE == 2 || MODE == 4 ? waves_per_simd / 2.0 : (MODE == 0 ? 0 : waves_per_simd);
   const double cyc = ms * 1e-3 * 2.4e9 / iters;
   printf("%-44s waves/SIMD=%d  %8.1f cycles/iter   (asked per SIMD and iter: %4.0f MFMA = %5.0f cyc at 16, %5.0f VALU = %5.0f cyc at 4%s)\n",
          name, waves_per_simd, cyc, mf * waves_m, mf * waves_m * 16, vf * waves_v, vf * waves_v * (PK ? 8 : 4), PK ? "x2 (pk)" : "");
@@ -82,7 +89,7 @@ static void run(const char* name, int waves_per_simd, float* d) {
 
 int main() {
   float* d;
-  hipMalloc(&d, 4096);
+  hipMalloc(&d, 8192);
   for (int w : {1, 2, 4, 8}) {
     run<0, 1, false>("MFMA only", w, d);
     run<1, 1, false>("VALU only (64 v_fma)", w, d);
@@ -90,6 +97,9 @@ int main() {
     if (w >= 2) {
       run<2, 1, false>("odd waves MFMA, even waves 64 v_fma", w, d);
       run<2, 2, false>("odd waves MFMA, even waves 128 v_fma", w, d);
+      run<4, 1, false>("same SIMD: odd slots MFMA, even slots 64 v_fma", w, d);
+      run<4, 2, false>("same SIMD: odd slots MFMA, even slots 128 v_fma", w, d);
+      run<4, 1, true>("same SIMD: odd slots MFMA, even slots 64 v_pk_fma", w, d);
     }
     run<3, 1, false>("one wave: 1 MFMA : 4 v_fma interleaved", w, d);
     run<3, 2, false>("one wave: 1 MFMA : 8 v_fma interleaved", w, d);
