@@ -442,6 +442,8 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
 
 // ------------------------------------------------------------------------------- two-launch depth sort (msd) ---
 #include "ggd_msd_finish.inc"
+constexpr int MSD_DIGIT_BITS = 10;
+static_assert((1 << MSD_DIGIT_BITS) == GGD_MSD_BINS && GGD_MSD_SHIFT + MSD_DIGIT_BITS == 24 && GGD_MSD_BINS % (4 * RS_THREADS) == 0, "bucket digit = key bits SHIFT..23");
 // See ggd_common.h (GGD_MSD_*).  Launch 1: a tile partitions its own 4096 keys by bits 14..23 -- the ranking of a onesweep
 // pass with 1024 digits, but nothing is published and nobody is waited for: the tile's keys go, in digit order, to the tile's
 // own region of (keys_out, vals_out), and table[tile][digit] = (first slot inside the tile << 16 | count).
@@ -451,17 +453,23 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
 // verdict on the speculation: top byte constant and no bucket above GGD_MSD_CAP
 __device__ __forceinline__ void msd_piggy_block(const ggd_scan_piggy& pg, uint32_t* lds) {
   const uint2 tv = scan_info_block(pg.wg_info, pg.n_info, pg.block_sums, pg.n_valid, pg.d_total, pg.h_total, lds);
-  uint32_t acc[5] = {0u, 0u, 0u, 0u, 0u};
+  constexpr int NS = GGD_FOLD_REP_STRIDE / 256;   // 256-word slabs per replica: the bucket histogram, then the top byte's
+  uint32_t acc[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) acc[q] = 0u;
 #pragma unroll 4
   for (int r = 0; r < GGD_FOLD_REPS; ++r) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) acc[q] += pg.fold_hist[r * GGD_FOLD_REP_STRIDE + q * 256 + threadIdx.x];
+    for (int q = 0; q < NS; ++q) acc[q] += pg.fold_hist[r * GGD_FOLD_REP_STRIDE + q * 256 + threadIdx.x];
   }
+  bool over = false;
 #pragma unroll
-  for (int q = 0; q < 5; ++q) pg.fold_hist[q * 256 + threadIdx.x] = acc[q];
-  const int flat = __syncthreads_or(acc[4] == tv.y);   // (also: nothing kept)
-  const int big = __syncthreads_or(acc[0] > (uint32_t)GGD_MSD_CAP || acc[1] > (uint32_t)GGD_MSD_CAP ||
-                                   acc[2] > (uint32_t)GGD_MSD_CAP || acc[3] > (uint32_t)GGD_MSD_CAP);
+  for (int q = 0; q < NS; ++q) {
+    pg.fold_hist[q * 256 + threadIdx.x] = acc[q];
+    if (q < NS - 1) over = over || acc[q] > (uint32_t)GGD_MSD_CAP;
+  }
+  const int flat = __syncthreads_or(acc[NS - 1] == tv.y);   // (also: nothing kept)
+  const int big = __syncthreads_or(over);
   const unsigned long long ok = (flat && !big) ? 1ull : 0ull;
   if (threadIdx.x == 0) {
     if (pg.d_total) pg.d_total[2] = (uint32_t)(flat ? 1u : 0u) | ((uint32_t)ok << 1);
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_msd_partition_kernel(const ui
     const uint32_t d = (key[r] >> GGD_MSD_SHIFT) & (GGD_MSD_BINS - 1);
     uint64_t peers = __ballot(ok);
 #pragma unroll
-    for (int b = 0; b < 10; ++b) {
+    for (int b = 0; b < MSD_DIGIT_BITS; ++b) {
       const uint64_t m = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
@@ -514,23 +522,33 @@ __global__ __launch_bounds__(RS_THREADS) void sort_msd_partition_kernel(const ui
   __syncthreads();
   uint32_t ltot;
   {
-    // thread t owns digits 4 t .. 4 t + 3
-    uint4 c[4];
+    // thread t owns digits DPT t .. DPT t + DPT - 1 (in groups of four)
+    constexpr int DPT = GGD_MSD_BINS / RS_THREADS, G = DPT / 4;
+    uint4 c[G][4];
+    uint32_t mine = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) c[w] = *reinterpret_cast<const uint4*>(&s_cnt[w][4 * threadIdx.x]);
-    const uint32_t l0 = c[0].x + c[1].x + c[2].x + c[3].x, l1 = c[0].y + c[1].y + c[2].y + c[3].y;
-    const uint32_t l2 = c[0].z + c[1].z + c[2].z + c[3].z, l3 = c[0].w + c[1].w + c[2].w + c[3].w;
-    const uint32_t e0 = block_exclusive_scan_256(l0 + l1 + l2 + l3, &ltot, s_scan);   // contains __syncthreads
-    const uint32_t e1 = e0 + l0, e2 = e1 + l1, e3 = e2 + l2;
-    *reinterpret_cast<uint4*>(&s_cnt[0][4 * threadIdx.x]) = make_uint4(e0, e1, e2, e3);
-    *reinterpret_cast<uint4*>(&s_cnt[1][4 * threadIdx.x]) = make_uint4(e0 + c[0].x, e1 + c[0].y, e2 + c[0].z, e3 + c[0].w);
-    *reinterpret_cast<uint4*>(&s_cnt[2][4 * threadIdx.x]) =
-        make_uint4(e0 + c[0].x + c[1].x, e1 + c[0].y + c[1].y, e2 + c[0].z + c[1].z, e3 + c[0].w + c[1].w);
-    *reinterpret_cast<uint4*>(&s_cnt[3][4 * threadIdx.x]) =
-        make_uint4(e0 + c[0].x + c[1].x + c[2].x, e1 + c[0].y + c[1].y + c[2].y, e2 + c[0].z + c[1].z + c[2].z,
-                   e3 + c[0].w + c[1].w + c[2].w);
-    *reinterpret_cast<uint4*>(table + (size_t)tile * GGD_MSD_BINS + 4 * threadIdx.x) =
-        make_uint4((e0 << 16) | l0, (e1 << 16) | l1, (e2 << 16) | l2, (e3 << 16) | l3);
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        c[g][w] = *reinterpret_cast<const uint4*>(&s_cnt[w][DPT * threadIdx.x + 4 * g]);
+        mine += c[g][w].x + c[g][w].y + c[g][w].z + c[g][w].w;
+      }
+    uint32_t e = block_exclusive_scan_256(mine, &ltot, s_scan);   // contains __syncthreads
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const uint32_t l0 = c[g][0].x + c[g][1].x + c[g][2].x + c[g][3].x, l1 = c[g][0].y + c[g][1].y + c[g][2].y + c[g][3].y;
+      const uint32_t l2 = c[g][0].z + c[g][1].z + c[g][2].z + c[g][3].z, l3 = c[g][0].w + c[g][1].w + c[g][2].w + c[g][3].w;
+      const uint32_t e0 = e, e1 = e0 + l0, e2 = e1 + l1, e3 = e2 + l2;
+      e = e3 + l3;
+      uint4 run = make_uint4(e0, e1, e2, e3);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        *reinterpret_cast<uint4*>(&s_cnt[w][DPT * threadIdx.x + 4 * g]) = run;
+        run.x += c[g][w].x; run.y += c[g][w].y; run.z += c[g][w].z; run.w += c[g][w].w;
+      }
+      *reinterpret_cast<uint4*>(table + (size_t)tile * GGD_MSD_BINS + DPT * threadIdx.x + 4 * g) =
+          make_uint4((e0 << 16) | l0, (e1 << 16) | l1, (e2 << 16) | l2, (e3 << 16) | l3);
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -550,37 +568,46 @@ __global__ __launch_bounds__(RS_THREADS) void sort_msd_partition_kernel(const ui
 }
 
 // Launch 2 (see ggd_msd_finish.inc): the bucket's sorted run written to its final place (bucket bases = prefix of the histogram).
-__global__ __launch_bounds__(MSDF_THREADS) void sort_msd_finish_kernel(const uint32_t* __restrict__ keys_in,
+__global__ __launch_bounds__(MSDF_THREADS, 8) void sort_msd_finish_kernel(const uint32_t* __restrict__ keys_in,
                                                                        const uint32_t* __restrict__ vals_in,
                                                                        uint32_t* __restrict__ keys_out,
                                                                        uint32_t* __restrict__ vals_out,
-                                                                       const uint32_t* __restrict__ hist /* [1024] totals */,
+                                                                       const uint32_t* __restrict__ hist /* [GGD_MSD_BINS] totals */,
                                                                        const uint32_t* __restrict__ table, int ntiles) {
   __shared__ msd_lds L;
   const int tid = threadIdx.x;
   const uint32_t b = blockIdx.x;
+  // (everything the workgroup needs before it can gather -- its bucket's size, the histogram below it, its column of the table --
+  // is requested at once: as three dependent trips they were a third of a small bucket's lifetime)
   const uint32_t nb = hist[b];
+  constexpr int HPT = GGD_MSD_BINS / MSDF_THREADS;
+  uint32_t below = 0;
+#pragma unroll
+  for (int q = 0; q < HPT; ++q) { const uint32_t i = (uint32_t)(HPT * tid + q); const uint32_t h = hist[i]; if (i < b) below += h; }
+  const uint32_t e0 = tid < ntiles ? table[(size_t)tid * GGD_MSD_BINS + b] : 0u;
   if (nb == 0u) return;
   uint32_t base;
-  {
-    const uint32_t h = hist[tid];
-    block_exclusive_scan_1024((uint32_t)tid < b ? h : 0u, &base, L.part);
-  }
-  msd_bucket_pieces(L, table, ntiles, b);
-  if (nb > (uint32_t)GGD_MSD_CAP) {
+  block_exclusive_scan_1024(below, &base, L.part);
+  const bool oversized = nb > (uint32_t)GGD_MSD_CAP;
+  msd_bucket_pieces(L, table, ntiles, b, e0, oversized);
+  if (oversized) {
     // more keys than the workgroup holds: the frame's histogram check has already failed and the host renders the frame again --
     // but the kernels behind this one still run, so they must find a valid permutation: the pieces, gathered in tile order
     for (uint32_t p = tid; p < nb; p += MSDF_THREADS) {
-      const size_t src = msd_piece_src(L, ntiles, p);
+      const size_t src = msd_piece_src_big(L, table, b, ntiles, p);
       keys_out[(size_t)base + p] = keys_in[src];
       vals_out[(size_t)base + p] = vals_in[src];
     }
     return;
   }
-  msd_bucket_sort(L, keys_in, vals_in, ntiles, nb);
+  if (nb > (uint32_t)MSD_XCAP) {   // exchange through the bucket's slice of the output; pass 2 leaves the final order there
+    msd_bucket_sort<true, MSDF_ITEMS>(L, keys_in, vals_in, ntiles, nb, keys_out + base, vals_out + base);
+    return;
+  }
+  msd_bucket_sort<false, MSDX_ITEMS>(L, keys_in, vals_in, ntiles, nb, nullptr, nullptr);
   for (uint32_t p = tid; p < nb; p += MSDF_THREADS) {
     keys_out[(size_t)base + p] = L.kv[p];
-    vals_out[(size_t)base + p] = L.kv[GGD_MSD_CAP + p];
+    vals_out[(size_t)base + p] = L.kv[MSD_XCAP + p];
   }
 }
 

@@ -102,7 +102,7 @@ struct ggd_scan_piggy {
   int spec_flat = 0;                        // != 0: only three passes were launched -- set *flat_flag whatever the histogram says
   uint32_t* fold_hist = nullptr;            // the folded front end's histogram replicas: the workgroup that runs step 2 also adds
                                             // replicas 1 .. REPS-1 of passes 1 .. 3 into replica 0 (only pass 0 reads them all)
-  int msd = 0;                              // two-launch sort: fold_hist holds [1024 | 256] bins per replica, all summed into replica 0
+  int msd = 0;                              // two-launch sort: fold_hist holds [GGD_MSD_BINS | 256] bins per replica, all summed into replica 0
 };
 
 // The depth sort's histogram kernel folded into the preprocess kernel (single-call forward on the tile-binning path): every
@@ -113,8 +113,9 @@ struct ggd_scan_piggy {
 // to 64 | status words of the 4 passes]; two blocks alternate, each cleared by the preprocess of the frame before its use.
 constexpr int GGD_FOLD_REPS = 16;   // (32 / 16 / 8 replicas: 4114 / 4140 / 4150 frames per second at 1 M / 1024^2; 3907 workgroups over 8 would
                                     // keep one address busy 80 % of the kernel's time, 16 leaves a margin)
-constexpr int GGD_FOLD_REP_STRIDE = 5 * 256;   // ordinary frames: the four byte histograms [p * 256 + digit], 256 spare words;
-                                               // two-launch sort (below): [1024 bins of key bits 14..23 | 256 bins of the top byte]
+constexpr int GGD_MSD_SHIFT = 14, GGD_MSD_BINS = 1024, GGD_MSD_CAP = 12288, GGD_MSD_MAX_TILES = 2048, GGD_MSD_BAN = 64;   // (below)
+constexpr int GGD_FOLD_REP_STRIDE = GGD_MSD_BINS + 256;   // ordinary frames: the four byte histograms [p * 256 + digit] in the first
+                                               // 1024 words; two-launch sort: [1024 bins of key bits 14..23 | 256 bins of the top byte]
 // Two-launch depth sort (round 5; `msd` in ggd_fold / ggd_scan_piggy): when the keys' top byte is constant -- the precondition of
 // the three-pass speculation -- the 24 varying bits are ordered by ONE most-significant-digit partition and an in-LDS finish
 // instead of three onesweep passes with their cross-tile look-back (48 -> see DESIGN.md):
@@ -122,10 +123,11 @@ constexpr int GGD_FOLD_REP_STRIDE = 5 * 256;   // ordinary frames: the four byte
 //             them to its own region and a table {offset, count} per (tile, bucket) -- no dependency between tiles at all;
 //   launch 2  one 1024-thread workgroup per bucket gathers the bucket's pieces from all tiles in tile order (= index order),
 //             orders them by bits 0..13 with two stable counting passes in LDS and writes the run to its final place (bucket
-//             bases = prefix of the preprocess kernel's 1024-bin histogram).
+//             bases = prefix of the preprocess kernel's 1024-bin histogram).  (2048 buckets of bits 13..23 were measured: the
+//             head-like scene's 154 buckets of 6.7 k keys become 308 of 3.3 k and its finish 27 -> 21 us, but launch 1 pays
+//             + 3 us for the wider digit and the cube scene's 514 small buckets gain nothing: profiles/REJECTED.md.)
 // The host speculates (after GGD_FLAT_STREAK flat frames); the frame's own histograms verify (top byte constant, no bucket above
 // GGD_MSD_CAP) and a frame that fails is binned and blended again by the ordinary path (as for the skipped fourth pass).
-constexpr int GGD_MSD_SHIFT = 14, GGD_MSD_BINS = 1024, GGD_MSD_CAP = 12288, GGD_MSD_MAX_TILES = 2048, GGD_MSD_BAN = 64;
 constexpr int GGD_FOLD_ROWTOT = GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE + 64;   // REPS x 64 words: entries per tile ROW (grids of <= 64
                                                                            // rows), for the row binning's first level
 constexpr int GGD_FOLD_HEAD = GGD_FOLD_ROWTOT + GGD_FOLD_REPS * 64;        // words in front of the status words

@@ -263,7 +263,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     if (lane == 0) { s_red[wv] = tsum; s_red[4 + wv] = (uint32_t)__popcll(act); }
     __syncthreads();
     uint32_t* hist = fold.ctl + (blockIdx.x % GGD_FOLD_REPS) * GGD_FOLD_REP_STRIDE;
-    for (int b = threadIdx.x; b < GGD_FOLD_REP_STRIDE; b += 256) {
+    const int used = fold.msd ? GGD_FOLD_REP_STRIDE : 4 * 256;
+    for (int b = threadIdx.x; b < used; b += 256) {
       const uint32_t c = s_hist[b];
       if (c) atomicAdd(&hist[b], c);
     }
