@@ -456,6 +456,37 @@ def test_depth_sort_in_two_launches_after_a_streak_is_exact_and_an_oversized_buc
     ctx.set_option(_capi.OPT_MSD_SORT, 1)
 
 
+@pytest.mark.parametrize("squeeze,lo,hi", [(0.0125, 6000, 8000), (0.008, 8000, 12288)])
+def test_two_launch_sort_with_dense_buckets(native_lib, squeeze, lo, hi):
+    """The finish kernel's two larger forms: a bucket close to what it exchanges through LDS (8 elements per thread), and one
+    above that but inside GGD_MSD_CAP, which exchanges through its slice of the output arrays.  60 000 Gaussians squeezed towards
+    a plane facing the camera so that the ~22 000 visible depths fall into 3-4 buckets; lists and ranges equal the oracle's on
+    every frame, the two-launch sort runs (asserted) and no frame is rendered again."""
+    from gaussian_gan_decoder_amd import _capi
+    ctx = _capi.context_for(torch.device("cuda:0"))
+    d = scene_inputs(P=60000, size=256, lsm=-5.5, seed=43)
+    view = d["viewmatrix"]
+    fwd, cam_pos = view[:3, 2], torch.inverse(view)[3, :3]
+    rel = d["means3D"] - cam_pos
+    d["means3D"] = (d["means3D"] - (rel @ fwd - 2.7)[:, None] * fwd[None, :] * (1.0 - squeeze)).contiguous()
+    o = run_oracle(d)
+    dk = o["depths"][o["radii"] > 0].astype(np.float32).view(np.uint32)
+    biggest = np.bincount((dk >> 14) & 1023).max()
+    assert lo < biggest <= hi and len(np.unique(dk >> 24)) == 1, biggest                              # the premise
+    ctx.set_option(_capi.OPT_MSD_SORT, 1)
+    m0, r0 = ctx.get_option(_capi.STAT_MSD_FRAMES), ctx.get_option(_capi.STAT_SORT_RERUNS)
+    for i in range(80):
+        n = run_native(d, debug=False)
+        assert n["num_rendered"] == o["num_rendered"], i
+        np.testing.assert_array_equal(n["point_list"], o["point_list"], err_msg=f"frame {i}")
+        np.testing.assert_array_equal(n["ranges"], o["ranges"], err_msg=f"frame {i}")
+        if ctx.get_option(_capi.STAT_MSD_FRAMES) >= m0 + 3:
+            break
+    assert ctx.get_option(_capi.STAT_MSD_FRAMES) >= m0 + 3, "the two-launch sort never ran (a pause left by an earlier test lasts 64 frames)"
+    assert ctx.get_option(_capi.STAT_SORT_RERUNS) == r0
+    assert_blend_matches(n, o)
+
+
 @pytest.mark.parametrize("W,H,P", [(1100, 48, 6000), (40, 1090, 6000), (333, 333, 20000), (17, 33, 300), (1040, 1040, 150000)])
 def test_two_launch_sort_on_odd_and_wide_grids(native_lib, W, H, P):
     """The two-launch depth sort under the binning forms it can meet: grids wider / taller than 64 tiles (the wide row / column
