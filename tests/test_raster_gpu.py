@@ -456,6 +456,37 @@ def test_depth_sort_in_two_launches_after_a_streak_is_exact_and_an_oversized_buc
     ctx.set_option(_capi.OPT_MSD_SORT, 1)
 
 
+def test_two_launch_sort_when_every_key_of_a_sort_tile_is_kept(native_lib):
+    """Every Gaussian on screen (what the decoder's training scenes look like): all 4096 keys of a sort tile are kept, so the
+    empty pieces behind a tile's last key start at slot 4096 -- one more than the 12 bits the finish kernel packs a piece's slot
+    into.  (Unmasked, that carried into the piece's position, the binary search over the pieces lost its order, the sorted
+    order held duplicates and the binning overran: found as a GPU fault in the train step, round 5.)"""
+    from gaussian_gan_decoder_amd import _capi
+    ctx = _capi.context_for(torch.device("cuda:0"))
+    d = scene_inputs(P=30000, size=256, lsm=-5.5, seed=61)
+    d["means3D"] = (0.3 * d["means3D"]).contiguous()
+    # in depth order: a sort tile then holds one depth range, and for every deeper bucket its (empty) piece starts at slot 4096
+    view = d["viewmatrix"]
+    by_depth = torch.argsort(d["means3D"] @ view[:3, 2] + view[3, 2])
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        d[k] = d[k][by_depth].contiguous()
+    o = run_oracle(d)
+    dk = o["depths"].astype(np.float32).view(np.uint32)
+    assert (o["radii"] > 0).all() and len(np.unique((dk[:4096] >> 14) & 1023)) < len(np.unique((dk >> 14) & 1023))     # the premise
+    ctx.set_option(_capi.OPT_MSD_SORT, 1)
+    m0, r0 = ctx.get_option(_capi.STAT_MSD_FRAMES), ctx.get_option(_capi.STAT_SORT_RERUNS)
+    for i in range(80):
+        n = run_native(d, debug=False)
+        assert n["num_rendered"] == o["num_rendered"], i
+        np.testing.assert_array_equal(n["point_list"], o["point_list"], err_msg=f"frame {i}")
+        np.testing.assert_array_equal(n["ranges"], o["ranges"], err_msg=f"frame {i}")
+        if ctx.get_option(_capi.STAT_MSD_FRAMES) >= m0 + 3:
+            break
+    assert ctx.get_option(_capi.STAT_MSD_FRAMES) >= m0 + 3, "the two-launch sort never ran (a pause left by an earlier test lasts 64 frames)"
+    assert ctx.get_option(_capi.STAT_SORT_RERUNS) == r0
+    assert_blend_matches(n, o)
+
+
 @pytest.mark.parametrize("squeeze,lo,hi", [(0.0125, 6000, 8000), (0.008, 8000, 12288)])
 def test_two_launch_sort_with_dense_buckets(native_lib, squeeze, lo, hi):
     """The finish kernel's two larger forms: a bucket close to what it exchanges through LDS (8 elements per thread), and one
