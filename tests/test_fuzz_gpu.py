@@ -107,3 +107,57 @@ def test_random_configuration_matches_oracle(native_lib, seed):
         for k, v in zip(keys, saved):
             cx.set_option(k, v)
         cx.set_option(_capi.OPT_BINNING, 1)
+
+
+def _sort_case(seed):
+    """Scenes of several depth-sort tiles (4096 keys each) for the two-launch sort: all or part of the Gaussians on screen, the
+    input in random / ascending / descending depth order (a sort tile then holds one depth range and most of its pieces are
+    empty), depths spread over many buckets or squeezed into a few."""
+    rng = np.random.RandomState(7000 + seed)
+    P = int(rng.choice([9000, 12288, 20000, 33000, 70000])) if seed % 4 != 1 else int(rng.choice([33000, 70000]))
+    W, H = [(256, 256), (200, 136), (320, 96)][rng.randint(3)]
+    d = scene_inputs(P=P, size=max(W, H), kind=str(rng.choice(["cube", "shell"])), seed=300 + seed, lsm=float(rng.uniform(-6.0, -4.5)),
+                     fov_deg=float(rng.uniform(8.0, 16.0)), width=W, height=H)
+    zoom = float(rng.choice([0.25, 0.5, 1.0])) if seed % 4 != 1 else 0.25
+    d["means3D"] = (zoom * d["means3D"]).contiguous()                                        # 0.25: everything on screen
+    view = d["viewmatrix"]
+    fwd = view[:3, 2]
+    depth = d["means3D"] @ fwd + view[3, 2]
+    squeeze = float(rng.choice([1.0, 1.0, 0.1, 0.02])) if seed % 4 != 1 else float(rng.choice([1.0, 0.1]))
+    d["means3D"] = (d["means3D"] - ((depth - 2.7) * (1.0 - squeeze))[:, None] * fwd[None, :]).contiguous()
+    order = str(rng.choice(["random", "ascending", "descending"]))
+    if seed % 4 == 1:   # every fourth case: >= 8 fully kept sort tiles in ascending depth order (each tile one depth range)
+        order = "ascending"
+    if order != "random":
+        perm = torch.argsort(d["means3D"] @ fwd + view[3, 2], descending=order == "descending")
+        for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+            d[k] = d[k][perm].contiguous()
+    return d, dict(P=P, W=W, H=H, squeeze=squeeze, order=order)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_two_launch_sort_on_random_multi_tile_scenes(native_lib, seed):
+    from gaussian_gan_decoder_amd import _capi
+    from _util import assert_blend_matches
+    d, what = _sort_case(seed)
+    o = run_oracle(d)
+    dk = o["depths"][o["radii"] > 0].astype(np.float32).view(np.uint32)
+    if len(dk) == 0 or len(np.unique(dk >> 24)) != 1:
+        pytest.skip("the scene's depths cross a binade: the two-launch sort does not apply")
+    oversized = np.bincount((dk >> 14) & 1023).max() > 12288
+    cx = _capi.context_for(torch.device("cuda:0"))
+    saved = cx.get_option(_capi.OPT_MSD_SORT)
+    cx.set_option(_capi.OPT_MSD_SORT, 1)
+    try:
+        m0 = cx.get_option(_capi.STAT_MSD_FRAMES)
+        for i in range(12 if oversized else 80):
+            n = run_native(d, debug=False)
+            assert n["num_rendered"] == o["num_rendered"], (what, i)
+            np.testing.assert_array_equal(n["point_list"], o["point_list"], err_msg=f"{what} frame {i}")
+            np.testing.assert_array_equal(n["ranges"], o["ranges"], err_msg=f"{what} frame {i}")
+            if cx.get_option(_capi.STAT_MSD_FRAMES) >= m0 + 2:
+                break
+        assert oversized or cx.get_option(_capi.STAT_MSD_FRAMES) >= m0 + 2, what
+        assert_blend_matches(n, o)
+    finally:
+        cx.set_option(_capi.OPT_MSD_SORT, saved)
