@@ -41,9 +41,15 @@ __device__ __forceinline__ f2 gauss_power2(float hA, float nBdy, float hCdy2, f2
 }
 
 // exp() variants for the blend (GGD_OPT_EXP_MODE).
+// The bare hardware exponential, written out: ONE expression shared by the forward (mode 1, and the forward half of the default
+// mode 3) and by the backward's contribution decision (bwd_update<3>), so that the two passes cannot drift apart with the way a
+// ROCm release lowers __expf: v_exp_f32(fl(x * log2e)), ~3 ulp on [-6, 0].
+constexpr float BLEND_LOG2E = 1.44269502162933349609375f;
+__device__ __forceinline__ float blend_exp_bare(float x) { return __builtin_amdgcn_exp2f(x * BLEND_LOG2E); }
+
 template <int MODE>
 __device__ __forceinline__ float blend_exp(float x) {
-  if (MODE == 1) return __expf(x);  // v_exp_f32(x * log2e): ~3 ulp on [-6, 0]
+  if (MODE == 1) return blend_exp_bare(x);
   if (MODE == 2) {                  // 2^(hi) * (1 + lo*ln2): hi = fl(x*log2e), lo = exact product residual + low bits
     const float t = x * 1.44269502162933349609375f;
     float lo = __builtin_fmaf(x, 1.44269502162933349609375f, -t);
@@ -491,10 +497,10 @@ __device__ __forceinline__ uint64_t bwd_update(BwdPixel& st, float pw, float dx,
     // ulp of the floor is then in or out in both passes, and the transmittance replayed by T / (1 - alpha) stays consistent
     // with the saved final_T (decided on the accurate value, the two passes could disagree on such a record, 0.4 %
     // on everything in front of it in that pixel) -- while the VALUES use the compensated exponential.
-    const float t = pw * 1.44269502162933349609375f;
-    float lo = __builtin_fmaf(pw, 1.44269502162933349609375f, -t);
+    const float t = pw * BLEND_LOG2E;
+    float lo = __builtin_fmaf(pw, BLEND_LOG2E, -t);
     lo = __builtin_fmaf(pw, 1.925963033500011e-08f, lo);
-    const float e = __builtin_amdgcn_exp2f(t);
+    const float e = blend_exp_bare(pw);          // == the forward's G, by construction (the compiler shares the product t)
     adec = fminf(0.99f, e * opacity);
     g0 = __builtin_fmaf(e, lo * 0.693147182464599609375f, e);
   } else {

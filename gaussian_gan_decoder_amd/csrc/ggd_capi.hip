@@ -257,6 +257,7 @@ static int check_inputs(ggd_ctx* ctx, const ggd_params* prm, const float* means3
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------
+static const char* const kPendingMsg = "a frame enqueued with ggd_forward_enqueue is pending on this context: call ggd_forward_collect first";
 // Enqueue the per-Gaussian kernels + scan + the asynchronous read-back of {R, prefilter trap}; no host sync.
 static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D,
                             const float* shs, const float* colors_precomp, const float* opacities,
@@ -431,6 +432,7 @@ extern "C" int ggd_forward_geometry(ggd_ctx* ctx, void* stream, const ggd_params
                                     const float* shs, const float* colors_precomp, const float* opacities,
                                     const float* scales, const float* rotations, const float* cov3D_precomp,
                                     void* geom_buf, int32_t* radii, int64_t* num_rendered) {
+  if (ctx && ctx->pending.valid) return ggd_fail(ctx, GGD_E_INVALID, kPendingMsg);
   const int rc = geometry_enqueue(ctx, stream, prm, means3D, shs, colors_precomp, opacities, scales, rotations,
                                   cov3D_precomp, geom_buf, radii, num_rendered);
   if (rc != GGD_OK || prm->P == 0) return rc;
@@ -605,6 +607,10 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
 
 extern "C" int ggd_forward_render(ggd_ctx* ctx, void* stream, const ggd_params* prm, const void* geom_buf,
                                   int64_t R, void* binning_buf, void* img_buf, float* out_color) {
+  // (the speculation state of a frame between ggd_forward_enqueue and ggd_forward_collect -- spec3, msd_frame, frame_folded, the
+  // tagged read-back -- lives on the context: another forward on it would clear that state and a missed speculation would
+  // never be rendered again)
+  if (ctx && ctx->pending.valid) return ggd_fail(ctx, GGD_E_INVALID, kPendingMsg);
   return render_enqueue(ctx, stream, prm, geom_buf, R, R, binning_buf, img_buf, out_color, false);
 }
 
@@ -655,7 +661,7 @@ extern "C" int ggd_forward(ggd_ctx* ctx, void* stream, const ggd_params* prm, co
                            void* binning_buf, int64_t capacity, void* img_buf, float* out_color,
                            int64_t* num_rendered) {
   if (capacity < 0) return ggd_fail(ctx, GGD_E_INVALID, "capacity < 0");
-  if (ctx) ctx->pending.valid = false;
+  if (ctx && ctx->pending.valid) return ggd_fail(ctx, GGD_E_INVALID, kPendingMsg);
   if (prm && prm->P > 0 && capacity > 0 && ggd_forward_can_speculate(ctx, prm, capacity)) {
     const int rc = forward_spec_enqueue(ctx, stream, prm, means3D, shs, colors_precomp, opacities, scales, rotations,
                                         cov3D_precomp, geom_buf, radii, binning_buf, capacity, img_buf, out_color, num_rendered);

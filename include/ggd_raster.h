@@ -171,8 +171,10 @@ int ggd_forward(ggd_ctx* ctx, void* stream, const ggd_params* prm,
  * ggd_forward_enqueue launches the whole frame and returns at once; it needs the speculative route (ggd_forward_can_speculate,
  * P > 0, capacity > 0).  ggd_forward_collect, called any time later on the same context (typically when the slot comes round
  * again, the frame long finished), returns that frame's num_rendered -- or GGD_E_CAPACITY with it, in which case the outputs
- * are not valid and the frame has to be rendered again with a larger buffer.  At most one frame per context may be pending;
- * the buffers, the camera matrices and the other pointers of `prm` must stay valid until it is collected.
+ * are not valid and the frame has to be rendered again with a larger buffer.  At most one frame per context may be pending:
+ * while one is, ggd_forward / ggd_forward_geometry / ggd_forward_render / ggd_forward_enqueue on that context return
+ * GGD_E_INVALID (the pending frame's verification state lives on the context).  The buffers, the camera matrices and the other
+ * pointers of `prm` must stay valid until it is collected.
  */
 int ggd_forward_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm,
                         const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,

@@ -11,7 +11,7 @@
 #   train_fp32/ kernel trace of the train step with the reference-precision fused decoder
 #   hd/         kernel trace of scripts/hd_timing.py (1080p, 2048^2, 4K: every binning path that applies)
 set -u
-TAG=${1:-r03_final}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
@@ -33,7 +33,7 @@ cd $R
 # (14 frames: the two-launch depth sort starts after 8 flat frames)
 bash scripts/pmc_passes.sh $TAG/pmc scripts/fwd_only.py 1M_1024_cube 14 --backward > /dev/null
 bash scripts/pmc_passes.sh $TAG/pmc_shell scripts/fwd_only.py 1M_1024_shell 14 --backward > /dev/null
-bash scripts/pmc_passes.sh $TAG/pmc_mlp scripts/mlp_only.py 5 > /dev/null
+bash scripts/pmc_passes.sh $TAG/pmc_mlp scripts/mlp_only.py 40 > /dev/null
 bash scripts/pmc_passes.sh $TAG/pmc_hl scripts/hl_only.py 3 > /dev/null
 bash scripts/frame_traces.sh gpurun_out/$TAG > /dev/null 2>&1
 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench_plain.err

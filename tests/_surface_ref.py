@@ -81,3 +81,45 @@ def point_random_numbers(seed, idx):
     g1, g2 = _u01(h1 >> np.uint64(24)), _u01(_mix64(h1))
     gauss = np.sqrt(np.float32(-2.0) * np.log(g1)) * np.cos(np.float32(6.283185307179586) * g2)
     return r0 / rs, r1 / rs, r2 / rs, gauss.astype(np.float32)
+
+
+def all_triangles(sigma, level):
+    """Every triangle of the marching-tetrahedra surface, vectorised (the SET the kernel samples from, not its face numbering):
+    float64 [F, 3, 3] vertices in index coordinates.  len == cell_face_counts(...).sum()."""
+    n = sigma.shape[0]; m = n - 1
+    f = corner_values(sigma, level).astype(np.float64)                      # [cells, 8]
+    cell = np.arange(f.shape[0])
+    origin = np.stack([cell // (m * m), (cell // m) % m, cell % m], 1).astype(np.float64)
+    corner = CORNER.astype(np.float64)
+    out = []
+
+    def edge(fc, rows, a, b):                                              # a, b: per-row corner ids
+        fa, fb = fc[rows, a], fc[rows, b]
+        t = (fa / (fa - fb))[:, None]
+        return corner[a] + t * (corner[b] - corner[a])
+    for t in range(6):
+        ids = TET[t]
+        inside = f[:, ids] > 0
+        k = inside.sum(1)
+        for kk in (1, 2, 3):
+            rows = np.nonzero(k == kk)[0]
+            if rows.size == 0:
+                continue
+            ins = inside[rows]
+            # stable order: the `kk` inside vertices first (kk = 1, 2) / the outside vertex first (kk = 3), each group in TET order
+            key = ~ins if kk in (1, 2) else ins
+            order = np.argsort(key, axis=1, kind="stable")
+            v = ids[order]                                                 # [rows, 4] corner ids
+            if kk in (1, 3):
+                tri = np.stack([edge(f, rows, v[:, 0], v[:, j]) for j in (1, 2, 3)], 1)
+                out.append(tri + origin[rows][:, None, :])
+            else:
+                p, q, r, s2 = v[:, 0], v[:, 1], v[:, 2], v[:, 3]
+                e_pr, e_ps, e_qs, e_qr = edge(f, rows, p, r), edge(f, rows, p, s2), edge(f, rows, q, s2), edge(f, rows, q, r)
+                out.append(np.stack([e_pr, e_ps, e_qs], 1) + origin[rows][:, None, :])
+                out.append(np.stack([e_pr, e_qs, e_qr], 1) + origin[rows][:, None, :])
+    return np.concatenate(out, 0) if out else np.zeros((0, 3, 3))
+
+
+def triangle_areas(tri):
+    return 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)

@@ -104,6 +104,38 @@ def run_native(d, device="cuda:0", debug=True, binning=None):
     return out
 
 
+def device_args(d, device="cuda:0", debug=False):
+    """The positional arguments of `rasterizer.rasterize_gaussians_native` / `FramePipeline.submit` for the inputs `d`, resident
+    on the device (a render loop that does not upload its scene every frame)."""
+    dev = torch.device(device)
+    t = lambda x: torch.empty(0, device=dev) if x is None else x.to(dev)
+    return (t(d["bg"]), t(d["means3D"]), t(d["colors_precomp"]), t(d["opacities"]), t(d["scales"]), t(d["rotations"]),
+            d["scale_modifier"], t(d["cov3D_precomp"]), t(d["viewmatrix"]), t(d["projmatrix"]), d["tanfovx"], d["tanfovy"],
+            d["H"], d["W"], t(d["shs"]), d["sh_degree"], t(d["campos"]), False, debug)
+
+
+def decode_result(d, res):
+    """(num_rendered, color, radii, geom, binning, img[, event]) of a native forward -> the dict run_native returns."""
+    num_rendered, color, radii, geom, binning, img = res[:6]
+    out = dict(num_rendered=num_rendered, color=color, radii=radii, geom=geom, binning=binning, img=img)
+    out.update(decode_buffers(d["P"], d["W"], d["H"], num_rendered, geom, binning, img))
+    return out
+
+
+def same_frame(a, b):
+    """Two native forward results hold the same frame bit for bit: num_rendered, the sorted list, and the whole image buffer
+    (ranges, final_T, n_contrib), colour and radii -- compared on the device."""
+    from gaussian_gan_decoder_amd import _capi
+    R = a[0]
+    if not (R == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[4][:4 * R], b[4][:4 * R])):
+        return False
+    H, W = a[1].shape[-2:]
+    iv = _capi.img_view(W, H)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    return all(torch.equal(a[5][o:o + n], b[5][o:o + n])
+               for o, n in ((iv.ranges, 8 * T), (iv.final_T, 4 * W * H), (iv.n_contrib, 4 * W * H)))
+
+
 def decode_buffers(P, W, H, R, geom, binning, img):
     """`keys` is only meaningful when the forward ran with debug=True (radix-sort path, buffer laid out for exactly R);
     the sorted list is at offset 0 of the binning buffer whatever capacity it was allocated for."""

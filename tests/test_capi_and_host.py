@@ -113,3 +113,29 @@ def test_gaussian_model_getters_and_sh_helpers():
         ref = O.cov3d(pc.get_scaling[i].numpy(), 1.3, pc.get_rotation[i].numpy())
         assert torch.allclose(cov[i], torch.from_numpy(ref), rtol=1e-4, atol=1e-8)
     assert abs(sh.SH2RGB(sh.RGB2SH(torch.tensor(0.3))).item() - 0.3) < 1e-6
+
+
+def test_kernel_register_and_lds_budgets(native_lib):
+    """The occupancy figures DESIGN.md builds on, read from the code objects inside the built library (no GPU needed;
+    scripts/kernel_resources.py): kernels whose inline asm names FIXED physical registers v[248:255] (gt_lin4 in
+    ggd_mlp_gelu.inc) must own a 256-VGPR allocation; the forward blend and the sort's finish kernel must keep the
+    register / LDS budgets of 8 waves per SIMD and two workgroups per CU; no hot raster kernel may spill."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "scripts", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec); spec.loader.exec_module(kr)
+    from gaussian_gan_decoder_amd import _capi
+    tab = {kr.short(k): v for k, v in kr.kernel_resources(_capi.LIB_PATH).items()}
+    assert len(tab) > 60, "could not read the kernels' metadata out of the library"
+    find = lambda prefix: {k: v for k, v in tab.items() if k.startswith(prefix)}
+    for name, r in {**find("decoder_forward_hl_kernel"), **find("decoder_backward_hl_kernel")}.items():
+        assert r["vgpr"] == 256, f"{name} uses fixed registers v[248:255] but allocates {r['vgpr']} VGPRs"
+        assert r["vgpr_spill"] <= 16, (name, r)
+    fwd = find("blend_forward_kernel")
+    assert fwd and all(r["vgpr"] <= 64 and r["vgpr_spill"] == 0 and r["lds"] <= 4096 for r in fwd.values()), fwd
+    fin = find("sort_msd_finish_kernel")
+    assert fin and all(r["vgpr"] <= 64 and r["lds"] <= 80 * 1024 + 512 and r["vgpr_spill"] == 0 for r in fin.values()), fin
+    for prefix in ("preprocess_kernel", "sort_msd_partition_kernel", "rb_level1_kernel", "rb_scatter2_kernel", "rb_count2_kernel",
+                   "rb_scan2_kernel", "blend_backward_quarter_kernel", "blend_backward_tile_kernel", "preprocess_backward_kernel"):
+        ks = find(prefix)
+        assert ks, prefix
+        assert all(r["vgpr_spill"] == 0 and r["scratch"] == 0 for r in ks.values()), (prefix, ks)
