@@ -225,6 +225,23 @@ __global__ __launch_bounds__(RS_THREADS) void sort_global_hist_kernel(const KeyT
   if (SKIP && n_valid && my_valid) atomicAdd(n_valid, my_valid);
 }
 
+// The kept keys' range of this frame (GGD_FOLD_MINMAX replicas, filled by the preprocess kernel): reduced by the first wave of the
+// workgroup that delivers num_rendered and stored -- BEFORE the tagged word's release store, by the same thread -- into
+// d_total[3..5] and the pinned words 4..6: {min key, max key, flags (bit 0: top byte constant, 1: no key outside the two-launch
+// sort's window, 2: no bucket above its capacity)}.  The host fits the next frames' window to these ranges.
+__device__ __forceinline__ void fold_publish_range(const ggd_scan_piggy& pg, uint32_t flags) {
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  uint32_t v = lane < 2 * GGD_FOLD_REPS ? pg.fold_hist[GGD_FOLD_MINMAX + (lane >> 1) * GGD_FOLD_MINMAX_STRIDE + (lane & 1)] : 0u;   // even lanes ~min, odd lanes max
+#pragma unroll
+  for (int sh = 2; sh < 2 * GGD_FOLD_REPS; sh <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, sh, 64));
+  const uint32_t nmin = (uint32_t)__shfl((int)v, 0, 64), kmax = (uint32_t)__shfl((int)v, 1, 64);
+  if (lane == 0) {
+    if (pg.d_total) { pg.d_total[3] = ~nmin; pg.d_total[4] = kmax; pg.d_total[5] = flags; }
+    if (pg.h_total) { pg.h_total[4] = ~nmin; pg.h_total[5] = kmax; pg.h_total[6] = flags; }
+  }
+}
+
 // COMPACT (depth sort): pass 0 (IOTA) drops keys equal to ~0 -- they are neither ranked nor written -- and every later
 // pass takes its element count from *n_dev (= number of kept keys, written by the histogram kernel).  A later pass
 // whose digit is the same for all elements (ghist[d] == n: e.g. the exponent byte of a scene's depth range) degrades to
@@ -258,6 +275,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
           pg.fold_hist[p * RS_BINS + threadIdx.x] = acc[p - 1];
         }
         flat = __syncthreads_or(acc[2] == tv.y);   // the top digit of every kept key is the same (also: nothing kept)
+        fold_publish_range(pg, flat ? 1u : 0u);
       }
       if (threadIdx.x == 0) {
         if (pg.spec_flat && pg.flat_flag) *pg.flat_flag = 1u;
@@ -443,14 +461,15 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
 // ------------------------------------------------------------------------------- two-launch depth sort (msd) ---
 #include "ggd_msd_finish.inc"
 constexpr int MSD_DIGIT_BITS = 10;
-static_assert((1 << MSD_DIGIT_BITS) == GGD_MSD_BINS && GGD_MSD_SHIFT + MSD_DIGIT_BITS == 24 && GGD_MSD_BINS % (4 * RS_THREADS) == 0, "bucket digit = key bits SHIFT..23");
-// See ggd_common.h (GGD_MSD_*).  Launch 1: a tile partitions its own 4096 keys by bits 14..23 -- the ranking of a onesweep
+static_assert((1 << MSD_DIGIT_BITS) == GGD_MSD_BINS && GGD_MSD_BINS % (4 * RS_THREADS) == 0, "1024 buckets");
+// See ggd_common.h (GGD_MSD_*).  Launch 1: a tile partitions its own 4096 keys by their bucket in the key window -- the ranking of a onesweep
 // pass with 1024 digits, but nothing is published and nobody is waited for: the tile's keys go, in digit order, to the tile's
 // own region of (keys_out, vals_out), and table[tile][digit] = (first slot inside the tile << 16 | count).
 
 // the workgroup appended to launch 1: step 2 of the offsets scan (as in the onesweep form), the sum of the histogram replicas
 // (nobody else reads them during this launch: the totals go to replica 0, where launch 2 reads its bucket bases), and the
-// verdict on the speculation: top byte constant and no bucket above GGD_MSD_CAP
+// verdict on the speculation: no kept key outside the window and no bucket above GGD_MSD_CAP (bit 62 of the tagged word; bit 63
+// keeps saying "top byte constant", for the three-pass form's streak)
 __device__ __forceinline__ void msd_piggy_block(const ggd_scan_piggy& pg, uint32_t* lds) {
   const uint2 tv = scan_info_block(pg.wg_info, pg.n_info, pg.block_sums, pg.n_valid, pg.d_total, pg.h_total, lds);
   constexpr int NS = GGD_FOLD_REP_STRIDE / 256;   // 256-word slabs per replica: the bucket histogram, then the top byte's
@@ -470,7 +489,9 @@ __device__ __forceinline__ void msd_piggy_block(const ggd_scan_piggy& pg, uint32
   }
   const int flat = __syncthreads_or(acc[NS - 1] == tv.y);   // (also: nothing kept)
   const int big = __syncthreads_or(over);
-  const unsigned long long ok = (flat && !big) ? 1ull : 0ull;
+  const bool inside = pg.fold_hist[GGD_FOLD_OUTSIDE] == 0u;
+  const unsigned long long ok = (inside && !big) ? 1ull : 0ull;
+  fold_publish_range(pg, (flat ? 1u : 0u) | (inside ? 2u : 0u) | (big ? 0u : 4u));
   if (threadIdx.x == 0) {
     if (pg.d_total) pg.d_total[2] = (uint32_t)(flat ? 1u : 0u) | ((uint32_t)ok << 1);
     if (pg.h_tagged)
@@ -484,7 +505,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_msd_partition_kernel(const ui
                                                                         uint32_t* __restrict__ keys_out,
                                                                         uint32_t* __restrict__ vals_out, int64_t n,
                                                                         uint32_t* __restrict__ table, int ntiles,
-                                                                        ggd_scan_piggy pg) {
+                                                                        uint32_t lo, int shift, ggd_scan_piggy pg) {
   __shared__ uint32_t s_cnt[4][GGD_MSD_BINS];
   __shared__ uint32_t s_keys[MSD_TILE];
   __shared__ uint32_t s_vals[MSD_TILE];
@@ -499,13 +520,25 @@ __global__ __launch_bounds__(RS_THREADS) void sort_msd_partition_kernel(const ui
     const int64_t idx = wbase + r * 64 + lane;
     key[r] = idx < n ? keys_in[idx] : 0xffffffffu;    // (0xFFFFFFFF = culled: dropped here, as in the onesweep form's pass 0)
   }
+  // from here on a kept key is its offset inside the window (what the finish kernel orders by its low `shift` bits), and its
+  // bucket the offset's high part, clamped (a key outside the window has already failed the frame: it only has to stay a member
+  // of a valid permutation, and the preprocess kernel's histogram clamps the same way)
+  uint32_t dig[MSD_ITEMS];
+#pragma unroll
+  for (int r = 0; r < MSD_ITEMS; ++r) {
+    const bool ok = key[r] != 0xffffffffu;
+    const uint32_t rel = key[r] - lo;
+    dig[r] = min(rel >> shift, (uint32_t)(GGD_MSD_BINS - 1));
+    key[r] = ok ? rel : 0xffffffffu;
+    if (!ok) dig[r] = 0xffffffffu;
+  }
   for (int b = threadIdx.x; b < 4 * GGD_MSD_BINS; b += RS_THREADS) (&s_cnt[0][0])[b] = 0;
   __syncthreads();
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int r = 0; r < MSD_ITEMS; ++r) {
-    const bool ok = key[r] != 0xffffffffu;
-    const uint32_t d = (key[r] >> GGD_MSD_SHIFT) & (GGD_MSD_BINS - 1);
+    const bool ok = dig[r] != 0xffffffffu;
+    const uint32_t d = dig[r] & (GGD_MSD_BINS - 1);
     uint64_t peers = __ballot(ok);
 #pragma unroll
     for (int b = 0; b < MSD_DIGIT_BITS; ++b) {
@@ -553,8 +586,8 @@ __global__ __launch_bounds__(RS_THREADS) void sort_msd_partition_kernel(const ui
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < MSD_ITEMS; ++r) {
-    if (key[r] != 0xffffffffu) {
-      const uint32_t d = (key[r] >> GGD_MSD_SHIFT) & (GGD_MSD_BINS - 1);
+    if (dig[r] != 0xffffffffu) {
+      const uint32_t d = dig[r];
       const uint32_t p = s_cnt[wv][d] + rank[r];
       s_keys[p] = key[r];
       s_vals[p] = (uint32_t)(wbase + r * 64 + lane);
@@ -568,12 +601,14 @@ __global__ __launch_bounds__(RS_THREADS) void sort_msd_partition_kernel(const ui
 }
 
 // Launch 2 (see ggd_msd_finish.inc): the bucket's sorted run written to its final place (bucket bases = prefix of the histogram).
+// (keys_out: only the exchange area of a bucket above MSD_XCAP -- nobody behind the sort reads sorted keys, the binning takes
+// the order of the indices)
 __global__ __launch_bounds__(MSDF_THREADS, 8) void sort_msd_finish_kernel(const uint32_t* __restrict__ keys_in,
                                                                        const uint32_t* __restrict__ vals_in,
                                                                        uint32_t* __restrict__ keys_out,
                                                                        uint32_t* __restrict__ vals_out,
                                                                        const uint32_t* __restrict__ hist /* [GGD_MSD_BINS] totals */,
-                                                                       const uint32_t* __restrict__ table, int ntiles) {
+                                                                       const uint32_t* __restrict__ table, int ntiles, int kshift) {
   __shared__ msd_lds L;
   const int tid = threadIdx.x;
   const uint32_t b = blockIdx.x;
@@ -595,20 +630,16 @@ __global__ __launch_bounds__(MSDF_THREADS, 8) void sort_msd_finish_kernel(const 
     // but the kernels behind this one still run, so they must find a valid permutation: the pieces, gathered in tile order
     for (uint32_t p = tid; p < nb; p += MSDF_THREADS) {
       const size_t src = msd_piece_src_big(L, table, b, ntiles, p);
-      keys_out[(size_t)base + p] = keys_in[src];
       vals_out[(size_t)base + p] = vals_in[src];
     }
     return;
   }
   if (nb > (uint32_t)MSD_XCAP) {   // exchange through the bucket's slice of the output; pass 2 leaves the final order there
-    msd_bucket_sort<true, MSDF_ITEMS>(L, keys_in, vals_in, ntiles, nb, keys_out + base, vals_out + base);
+    msd_bucket_sort<true, MSDF_ITEMS>(L, keys_in, vals_in, ntiles, nb, kshift, keys_out + base, vals_out + base);
     return;
   }
-  msd_bucket_sort<false, MSDX_ITEMS>(L, keys_in, vals_in, ntiles, nb, nullptr, nullptr);
-  for (uint32_t p = tid; p < nb; p += MSDF_THREADS) {
-    keys_out[(size_t)base + p] = L.kv[p];
-    vals_out[(size_t)base + p] = L.kv[MSD_XCAP + p];
-  }
+  msd_bucket_sort<false, MSDX_ITEMS>(L, keys_in, vals_in, ntiles, nb, kshift, nullptr, nullptr);
+  for (uint32_t p = tid; p < nb; p += MSDF_THREADS) vals_out[(size_t)base + p] = L.kv[MSD_XCAP + p];
 }
 
 // ------------------------------------------------------------------------------------------- tile ranges -----
@@ -802,12 +833,13 @@ int ggd_launch_sort32_msd(ggd_ctx* ctx, hipStream_t s, const uint32_t* keys_src,
     return ggd_fail(ctx, GGD_E_INVALID, "sort32 (two launches): needs the folded front end in its msd form");
   const int ntiles = (int)((n + MSD_TILE - 1) / MSD_TILE);
   uint32_t* tickets = fold->ctl + GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE;
+  if (fold->msd_shift < 0 || fold->msd_shift > GGD_MSD_MAX_SHIFT) return ggd_fail(ctx, GGD_E_INVALID, "sort32 (two launches): bucket shift out of range");
   ggd_scan_piggy pg = *piggy;
-  pg.n_valid = tickets + RS_MAX_PASSES; pg.fold_hist = fold->ctl; pg.msd = 1;
+  pg.n_valid = tickets + RS_MAX_PASSES; pg.fold_hist = fold->ctl; pg.msd = 1; pg.msd_lo = fold->msd_lo; pg.msd_shift = fold->msd_shift;
   hipLaunchKernelGGL(sort_msd_partition_kernel, dim3(ntiles + 1), dim3(RS_THREADS), 0, s, keys_src, keys_b, vals_b, n, table,
-                     ntiles, pg);
+                     ntiles, fold->msd_lo, fold->msd_shift, pg);
   hipLaunchKernelGGL(sort_msd_finish_kernel, dim3(GGD_MSD_BINS), dim3(MSDF_THREADS), 0, s, keys_b, vals_b, keys_a, vals_a,
-                     fold->ctl, table, ntiles);
+                     fold->ctl, table, ntiles, fold->msd_shift);
   GGD_HIP(hipGetLastError());
   return GGD_OK;
 }

@@ -114,6 +114,7 @@ extern "C" ggd_ctx* ggd_create(int device) {
   if (const char* e = getenv("GGD_BLEND_CULL")) ctx->opt[GGD_OPT_BLEND_CULL] = atoi(e) != 0;
   if (const char* e = getenv("GGD_FOLD")) ctx->opt[GGD_OPT_FOLD] = atoi(e) != 0;
   if (const char* e = getenv("GGD_MSD_SORT")) ctx->opt[GGD_OPT_MSD_SORT] = atoi(e) != 0;
+  if (const char* e = getenv("GGD_MSD_BUCKETS")) { const int v = atoi(e); if (v >= 16 && v <= GGD_MSD_BINS) ctx->msd_buckets = v; }   // timing experiments
   int prev = 0;
   (void)hipGetDevice(&prev);
   bool ok = hipSetDevice(device) == hipSuccess &&
@@ -171,6 +172,11 @@ extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
   if (option < 0 || option >= GGD_OPT_COUNT || value < 0 || value > kMax[option])
     return ggd_fail(ctx, GGD_E_INVALID, "ggd_set_option: unknown option or value");
   ctx->opt[option] = value;
+  if (option == GGD_OPT_MSD_SORT || option == GGD_OPT_FOLD) {
+    // (re)setting the sort options restarts the cross-frame speculation state: the window of recent key ranges, the pause after
+    // a miss, the flat-frame streak -- a caller (or a test) that switches forms gets a defined starting point
+    ctx->win_n = 0; ctx->win_pos = 0; ctx->msd_ban = 0; ctx->flat_streak = 0;
+  }
   return GGD_OK;
 }
 extern "C" int ggd_blend_stats(ggd_ctx* ctx, int enable, unsigned long long* out) {
@@ -257,6 +263,27 @@ static int check_inputs(ggd_ctx* ctx, const ggd_params* prm, const float* means3
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------
+// The two-launch depth sort's key window for the next frame: the union of the kept-key ranges of the last folded frames, a margin
+// of 1/8 of its width either side, and the smallest shift that spreads it over at most ctx->msd_buckets buckets.  False when no
+// range is known yet or the window is too wide for two 8-bit finishing passes.
+static bool msd_fit_window(const ggd_ctx* ctx, uint32_t* lo_out, int* shift_out) {
+  const int n = ctx->win_n < GGD_MSD_WIN ? ctx->win_n : GGD_MSD_WIN;
+  if (n <= 0) return false;
+  uint32_t lo = 0xffffffffu, hi = 0u;
+  for (int i = 0; i < n; ++i) { lo = ctx->win_lo[i] < lo ? ctx->win_lo[i] : lo; hi = ctx->win_hi[i] > hi ? ctx->win_hi[i] : hi; }
+  if (lo > hi) return false;
+  const uint64_t margin = ((uint64_t)(hi - lo) >> 3) + 4096u;
+  const uint64_t wlo = (uint64_t)lo > margin ? (uint64_t)lo - margin : 0u;
+  uint64_t whi = (uint64_t)hi + margin;
+  if (whi > 0xfffffffeull) whi = 0xfffffffeull;
+  const uint64_t span = whi - wlo;            // bucket of the largest key = span >> shift, must stay below the bucket count
+  int shift = 0;
+  while ((span >> shift) >= (uint64_t)ctx->msd_buckets) ++shift;
+  if (shift > GGD_MSD_MAX_SHIFT) return false;
+  *lo_out = (uint32_t)wlo; *shift_out = shift;
+  return true;
+}
+
 static const char* const kPendingMsg = "a frame enqueued with ggd_forward_enqueue is pending on this context: call ggd_forward_collect first";
 // Enqueue the per-Gaussian kernels + scan + the asynchronous read-back of {R, prefilter trap}; no host sync.
 static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, const float* means3D,
@@ -333,11 +360,12 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
     fold.clear_words = (uint32_t)ctx->foldctl_dirty[oth];
     fold.wg_info = reinterpret_cast<uint2*>(ctx->scan_sums + (((size_t)nwg + 1) & ~(size_t)1));
     fold.rows = ((prm->width + 15) / 16 <= 64 && (prm->height + 15) / 16 <= 64) ? 1 : 0;
-    // two-launch depth sort: speculated under the conditions of the three-pass form (render_enqueue: folded, tile binning,
-    // speculative, a streak of flat frames), decided HERE because it selects the histograms this launch builds
-    ctx->msd_frame = ctx->opt[GGD_OPT_MSD_SORT] != 0 && ctx->opt[GGD_OPT_FOLD] == 1 && ctx->flat_streak >= GGD_FLAT_STREAK &&
-                     ctx->msd_ban == 0 && ggd_sort32_msd_supported(prm->P);
+    // two-launch depth sort: speculated once the key ranges of GGD_FLAT_STREAK folded frames are known (render_enqueue: folded,
+    // tile binning, speculative), decided HERE because it selects the histograms this launch builds
+    ctx->msd_frame = ctx->opt[GGD_OPT_MSD_SORT] != 0 && ctx->opt[GGD_OPT_FOLD] == 1 && ctx->win_n >= GGD_FLAT_STREAK &&
+                     ctx->msd_ban == 0 && ggd_sort32_msd_supported(prm->P) && msd_fit_window(ctx, &ctx->msd_lo, &ctx->msd_shift);
     fold.msd = ctx->msd_frame ? 1 : 0;
+    fold.msd_lo = ctx->msd_lo; fold.msd_shift = ctx->msd_shift;
     ctx->foldctl_dirty[oth] = 0;       // (clean once this launch has run)
     ctx->foldctl_dirty[cur] = need;    // what this frame may write
     ctx->fold_cur = oth;
@@ -405,9 +433,10 @@ static int geometry_finish(ggd_ctx* ctx, void* stream, const ggd_params* prm, in
         if (q == hipSuccess) {
           v = *slot;
           if (((v >> 32) & 0x3fffffffull) != want) {
-            uint32_t w3[3] = {0u, 0u, 0u};
-            GGD_HIP(hipMemcpy(w3, ctx->d_words, sizeof(w3), hipMemcpyDeviceToHost));
-            v = ((unsigned long long)(w3[2] & 1u) << 63) | ((unsigned long long)((w3[2] >> 1) & 1u) << 62) | (want << 32) | w3[0];
+            uint32_t w6[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+            GGD_HIP(hipMemcpy(w6, ctx->d_words, sizeof(w6), hipMemcpyDeviceToHost));
+            v = ((unsigned long long)(w6[2] & 1u) << 63) | ((unsigned long long)((w6[2] >> 1) & 1u) << 62) | (want << 32) | w6[0];
+            ctx->h_words[4] = w6[3]; ctx->h_words[5] = w6[4]; ctx->h_words[6] = w6[5];
           }
           break;
         }
@@ -419,6 +448,9 @@ static int geometry_finish(ggd_ctx* ctx, void* stream, const ggd_params* prm, in
     ctx->h_words[0] = (uint32_t)v;
     ctx->frame_flat = (v >> 63) != 0ull;
     ctx->frame_msd_ok = ((v >> 62) & 1ull) != 0ull;
+    // (stored by the same device thread before the tagged word's release store; x86 loads are not reordered with earlier loads)
+    volatile uint32_t* hw = ctx->h_words;
+    ctx->frame_kmin = hw[4]; ctx->frame_kmax = hw[5]; ctx->frame_msd_flags = hw[6];
   } else {
     GGD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   }
@@ -531,11 +563,12 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
       // the fourth pass is an empty launch when the depths' top byte is constant: after GGD_FLAT_STREAK such frames it is not
       // launched; ggd_forward re-renders a frame for which that was wrong (frame_flat arrives with num_rendered)
       ctx->frame_folded = folded;
-      ctx->spec3 = folded && rowbin && speculative && ctx->flat_streak >= GGD_FLAT_STREAK && ctx->opt[GGD_OPT_FOLD] == 1;
       const bool msd = folded && ctx->msd_frame;   // (this call's preprocess built the two-launch sort's histograms)
-      if (msd && !ctx->spec3) return ggd_fail(ctx, GGD_E_INVALID, "internal: two-launch sort outside the speculative tile-binning path");
+      if (msd && !(rowbin && speculative)) return ggd_fail(ctx, GGD_E_INVALID, "internal: two-launch sort outside the speculative tile-binning path");
+      ctx->spec3 = !msd && folded && rowbin && speculative && ctx->flat_streak >= GGD_FLAT_STREAK && ctx->opt[GGD_OPT_FOLD] == 1;
       if (!msd) ctx->msd_frame = false;
       fold.msd = msd ? 1 : 0;
+      fold.msd_lo = ctx->msd_lo; fold.msd_shift = ctx->msd_shift;
       if (msd)
         rc = ggd_launch_sort32_msd(ctx, s, depth_keys, ka, va, kb, vb, prm->P,
                                    reinterpret_cast<uint32_t*>(sc + 4 * pairs + sort_tmp + bin_tmp), &pg, &fold);
@@ -631,6 +664,7 @@ static int forward_spec_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* pr
                             cov3D_precomp, geom_buf, radii, num_rendered, true);
   if (rc != GGD_OK) return rc;
   ctx->spec3 = false; ctx->frame_folded = false; ctx->frame_flat = false; ctx->frame_msd_ok = false;
+  ctx->frame_kmin = 0xffffffffu; ctx->frame_kmax = 0u; ctx->frame_msd_flags = 0u;
   return render_enqueue(ctx, stream, prm, geom_buf, capacity, capacity, binning_buf, img_buf, out_color, true);
 }
 // ... and the collection of num_rendered (+ "the depth keys' top byte was constant") once the launch that delivers it has run;
@@ -643,8 +677,20 @@ static int forward_spec_collect(ggd_ctx* ctx, void* stream, const ggd_params* pr
   ctx->spec3 = false; ctx->msd_frame = false;
   if (ctx->frame_folded) ctx->flat_streak = ctx->frame_flat ? (ctx->flat_streak < (1 << 30) ? ctx->flat_streak + 1 : ctx->flat_streak) : 0;
   if (ctx->frame_folded && ctx->msd_ban > 0) ctx->msd_ban -= 1;
-  const bool msd_missed = msd && !(ctx->frame_flat && ctx->frame_msd_ok);
-  if (msd_missed) ctx->msd_ban = GGD_MSD_BAN;   // (a bucket above the finish kernel's capacity, or a varying top byte)
+  const bool msd_missed = msd && !ctx->frame_msd_ok;
+  const bool msd_oversize = msd_missed && (ctx->frame_msd_flags & 4u) == 0u;   // a bucket above the finish kernel's capacity
+  if (msd_oversize) {
+    // the window was too coarse for this data (or the data has > GGD_MSD_CAP equal keys): forget the older frames' ranges and pause
+    ctx->msd_ban = GGD_MSD_BAN;
+    ctx->win_n = 0; ctx->win_pos = 0;
+  } else if (msd_missed) {
+    ctx->msd_ban = 2;   // a key outside the window: this frame's range joins the window below, the next frames fit again
+  }
+  if (ctx->frame_folded && ctx->frame_kmin <= ctx->frame_kmax) {   // (something was kept) -> the ring of recent key ranges
+    ctx->win_lo[ctx->win_pos] = ctx->frame_kmin; ctx->win_hi[ctx->win_pos] = ctx->frame_kmax;
+    ctx->win_pos = (ctx->win_pos + 1) % GGD_MSD_WIN;
+    if (ctx->win_n < (1 << 30)) ctx->win_n += 1;
+  }
   if (msd && !msd_missed) ctx->msd_frames += 1;
   if (*num_rendered > capacity)
     return ggd_fail(ctx, GGD_E_CAPACITY, "binning_buf capacity is below num_rendered: re-run with a larger buffer");

@@ -27,6 +27,13 @@ constexpr int GGD_STATS_MODE = 9;            // word: 0 = counters (atomics), 1 
 constexpr int GGD_STATS_HEAD = 16;           // first timeline slot (3 words per wave: start, end, listed << 32 | gathered)
 constexpr int GGD_STATS_MAX_WAVES = 1 << 17;
 
+// two-launch depth sort (described at ggd_fold below)
+constexpr int GGD_MSD_SHIFT = 14, GGD_MSD_BINS = 1024, GGD_MSD_CAP = 12288, GGD_MSD_MAX_TILES = 2048, GGD_MSD_BAN = 64;
+constexpr int GGD_MSD_WIN = 32, GGD_MSD_MAX_SHIFT = 16;   // frames whose key ranges form the window; two 8-bit passes finish a bucket
+constexpr int GGD_MSD_TARGET = 512;   // buckets the window is spread over: 512 = one resident round of the finish kernel (two workgroups
+                                      // per CU); measured at 1 M / 1024^2, sort stage cube / shell: 1024 -> 27.4 / 35.8 us, 512 -> 23.5 / 33.5,
+                                      // 256 -> 25.8 / 34.1 (gpurun_out r06b; round 5's fixed bits 14..23: 23.2 / 34.5)
+
 struct ggd_ctx {
   int device = 0;
   void* scratch = nullptr;      // grow-only device workspace (sort histograms, scan block sums, dL_dconic, ...)
@@ -59,6 +66,15 @@ struct ggd_ctx {
   bool frame_msd_ok = false;        // ... and they say the two-launch sort was valid for this frame (read with num_rendered)
   int msd_ban = 0;                  // frames to wait before speculating again after a frame it was not valid for
   unsigned long long msd_frames = 0;
+  // ... over a speculated KEY WINDOW (round 6): buckets = (key - msd_lo) >> msd_shift, window and shift fitted to the depth
+  // keys of the recent folded frames (their min / max arrive with num_rendered), so a depth range that straddles a binade
+  // (2.0: top byte 0x3F | 0x40) no longer falls back to the four-pass sort
+  uint32_t msd_lo = 0;              // this frame's window start and bucket shift
+  int msd_shift = GGD_MSD_SHIFT;
+  uint32_t win_lo[GGD_MSD_WIN], win_hi[GGD_MSD_WIN];   // ring: kept-key min / max of the last folded frames
+  int win_n = 0, win_pos = 0;
+  uint32_t frame_kmin = 0xffffffffu, frame_kmax = 0u, frame_msd_flags = 0u;   // read with num_rendered
+  int msd_buckets = GGD_MSD_TARGET; // buckets the window is spread over (GGD_MSD_BUCKETS: timing experiments)
   // ggd_forward_enqueue ... ggd_forward_collect: the frame whose num_rendered has not been collected yet
   struct { bool valid = false; ggd_params prm; const void* geom = nullptr; void* binning = nullptr; int64_t capacity = 0;
            void* img = nullptr; float* out = nullptr; } pending;
@@ -103,6 +119,8 @@ struct ggd_scan_piggy {
   uint32_t* fold_hist = nullptr;            // the folded front end's histogram replicas: the workgroup that runs step 2 also adds
                                             // replicas 1 .. REPS-1 of passes 1 .. 3 into replica 0 (only pass 0 reads them all)
   int msd = 0;                              // two-launch sort: fold_hist holds [GGD_MSD_BINS | 256] bins per replica, all summed into replica 0
+  uint32_t msd_lo = 0;                      // ... its key window (ggd_fold)
+  int msd_shift = GGD_MSD_SHIFT;
 };
 
 // The depth sort's histogram kernel folded into the preprocess kernel (single-call forward on the tile-binning path): every
@@ -113,31 +131,48 @@ struct ggd_scan_piggy {
 // to 64 | status words of the 4 passes]; two blocks alternate, each cleared by the preprocess of the frame before its use.
 constexpr int GGD_FOLD_REPS = 16;   // (32 / 16 / 8 replicas: 4114 / 4140 / 4150 frames per second at 1 M / 1024^2; 3907 workgroups over 8 would
                                     // keep one address busy 80 % of the kernel's time, 16 leaves a margin)
-constexpr int GGD_MSD_SHIFT = 14, GGD_MSD_BINS = 1024, GGD_MSD_CAP = 12288, GGD_MSD_MAX_TILES = 2048, GGD_MSD_BAN = 64;   // (below)
 constexpr int GGD_FOLD_REP_STRIDE = GGD_MSD_BINS + 256;   // ordinary frames: the four byte histograms [p * 256 + digit] in the first
-                                               // 1024 words; two-launch sort: [1024 bins of key bits 14..23 | 256 bins of the top byte]
-// Two-launch depth sort (round 5; `msd` in ggd_fold / ggd_scan_piggy): when the keys' top byte is constant -- the precondition of
-// the three-pass speculation -- the 24 varying bits are ordered by ONE most-significant-digit partition and an in-LDS finish
-// instead of three onesweep passes with their cross-tile look-back (48 -> see DESIGN.md):
-//   launch 1  every 4096-key tile partitions ITS OWN keys by bits 14..23 (1024 buckets, stable, culled keys dropped), writes
-//             them to its own region and a table {offset, count} per (tile, bucket) -- no dependency between tiles at all;
+                                               // 1024 words; two-launch sort: [1024 buckets of the key window | 256 bins of the top byte]
+// Two-launch depth sort (round 5; `msd` in ggd_fold / ggd_scan_piggy; the key WINDOW since round 6).  The kept keys of a frame lie
+// in a narrow range of the 32-bit key space (fp32 bits of depths between, say, 1.8 and 3.6): over a window [lo, lo + 1024 << shift)
+// that contains them they are ordered by ONE most-significant-digit partition and an in-LDS finish instead of three or four
+// onesweep passes with their cross-tile look-back (48 -> see DESIGN.md):
+//   launch 1  every 4096-key tile partitions ITS OWN keys by bucket = (key - lo) >> shift (1024 buckets, stable, culled keys
+//             dropped), writes (key - lo, index) to its own region and a table {offset, count} per (tile, bucket) -- no dependency
+//             between tiles at all;
 //   launch 2  one 1024-thread workgroup per bucket gathers the bucket's pieces from all tiles in tile order (= index order),
-//             orders them by bits 0..13 with two stable counting passes in LDS and writes the run to its final place (bucket
-//             bases = prefix of the preprocess kernel's 1024-bin histogram).  (2048 buckets of bits 13..23 were measured: the
-//             head-like scene's 154 buckets of 6.7 k keys become 308 of 3.3 k and its finish 27 -> 21 us, but launch 1 pays
-//             + 3 us for the wider digit and the cube scene's 514 small buckets gain nothing: profiles/REJECTED.md.)
-// The host speculates (after GGD_FLAT_STREAK flat frames); the frame's own histograms verify (top byte constant, no bucket above
-// GGD_MSD_CAP) and a frame that fails is binned and blended again by the ordinary path (as for the skipped fourth pass).
+//             orders them by the `shift` low bits of (key - lo) with (up to) two stable 8-bit counting passes in LDS and writes
+//             the run of indices to its final place (bucket bases = prefix of the preprocess kernel's 1024-bin histogram).
+// Round 5 fixed the window to one binade pair (bucket = key bits 14..23, precondition: a constant top byte).  That fails for a
+// depth range that straddles 2.0 -- which the reference's pose sampler produces (camera.py:6-35: radius 2.7, yaw +- 1 rad: the
+// unit cube's near corner comes to depth 1.83) -- and left a head-like scene's keys in 154 of the 1024 buckets.  Now the host
+// fits the window to the ranges of the last GGD_MSD_WIN folded frames (+ 1/8 margin either side; every frame's kept-key min / max
+// arrive with num_rendered) and the shift to the window (<= GGD_MSD_MAX_SHIFT: two 8-bit passes).  (2048 buckets were measured
+// in round 5: launch 1 pays + 3 us for the wider digit, profiles/REJECTED.md.)
+// The host speculates (after GGD_FLAT_STREAK folded frames); the frame's own front end verifies (no kept key outside the window:
+// GGD_FOLD_OUTSIDE == 0; no bucket above GGD_MSD_CAP) and a frame that fails is binned and blended again by the ordinary path (as
+// for the skipped fourth pass); a key outside the window is clamped into the last bucket, so the kernels behind always see a
+// valid permutation.
+// the 64 words behind the histograms: [8 tickets | n_valid | flat | pad | OUTSIDE (word 16, a line of its own): kept keys outside
+// the two-launch sort's window | pad]
+constexpr int GGD_FOLD_OUTSIDE = GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE + 16;
 constexpr int GGD_FOLD_ROWTOT = GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE + 64;   // REPS x 64 words: entries per tile ROW (grids of <= 64
                                                                            // rows), for the row binning's first level
-constexpr int GGD_FOLD_HEAD = GGD_FOLD_ROWTOT + GGD_FOLD_REPS * 64;        // words in front of the status words
+// {~min, max} of the kept keys (atomicMax both: the block starts zeroed), one replica per 64-byte LINE: atomics on one line
+// serialise at ~11 ns each -- with the 16 replicas packed into two lines the 7800 atomics of a 1 M-point frame cost the
+// preprocess kernel 30 us (round 6, first form) -- and a workgroup only issues them when its value beats the one it reads first
+constexpr int GGD_FOLD_MINMAX = GGD_FOLD_ROWTOT + GGD_FOLD_REPS * 64;
+constexpr int GGD_FOLD_MINMAX_STRIDE = 16;
+constexpr int GGD_FOLD_HEAD = GGD_FOLD_MINMAX + GGD_FOLD_REPS * GGD_FOLD_MINMAX_STRIDE;        // words in front of the status words
 struct ggd_fold {
   uint32_t* ctl = nullptr;        // this frame's control block (clean)
   uint32_t* clear = nullptr;      // the other block ...
   uint32_t clear_words = 0;       // ... and how much of it the preprocess clears for the next frame
   uint2* wg_info = nullptr;       // [ceil(P / 256)]
   int rows = 0;                   // != 0: also count the Gaussians per tile row (the grid has <= 64 rows)
-  int msd = 0;                    // != 0: histograms of the two-launch sort (key bits 14..23, top byte) instead of the four bytes
+  int msd = 0;                    // != 0: histograms of the two-launch sort (1024 buckets of the key window, top byte) instead of the four bytes
+  uint32_t msd_lo = 0;            // bucket of a kept key = min((key - msd_lo) >> msd_shift, 1023); a key for which the unclamped
+  int msd_shift = GGD_MSD_SHIFT;  // value exceeds 1023 (below the window: the difference wraps) is counted in GGD_FOLD_OUTSIDE
 };
 // control block: [head | sort status words of the 4 passes | level-1 binning status words]
 size_t ggd_fold_ctl_words(int64_t P);

@@ -30,12 +30,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     uint2* __restrict__ rect, uint32_t* __restrict__ trap_flag, uint32_t* __restrict__ zero_ptr, int zero_words,
     ggd_fold fold) {
   __shared__ uint32_t s_hist[FOLD ? GGD_FOLD_REP_STRIDE : 1];
-  __shared__ uint32_t s_red[FOLD ? 8 : 1];
+  __shared__ uint32_t s_red[FOLD ? 17 : 1];   // per wave: sum of tiles, kept keys, ~min key, max key; [16]: keys outside the window
   __shared__ int s_rowdiff[FOLD ? 65 : 1];
   if constexpr (FOLD) {
     for (uint32_t z = blockIdx.x * 256 + threadIdx.x; z < fold.clear_words; z += gridDim.x * 256) fold.clear[z] = 0u;
     for (int b = threadIdx.x; b < GGD_FOLD_REP_STRIDE; b += 256) s_hist[b] = 0u;
     if (threadIdx.x < 65) s_rowdiff[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_red[16] = 0u;
     __syncthreads();
   } else {
     // first kernel of a frame: its first workgroups also clear the depth sort's control block (no memset launch there)
@@ -226,8 +227,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
       // (as sort_global_hist_kernel: the two high bytes -- sign / exponent / leading mantissa bits of a depth -- are usually
       // shared by the whole wave: one lane adds the count instead of 64 conflicting LDS atomics)
       const int leader = __builtin_ctzll(act);
-      if (fold.msd) {   // two-launch sort: bits 14..23 (never shared by a wave) and the top byte (almost always)
-        if (visible) atomicAdd(&s_hist[(key >> GGD_MSD_SHIFT) & (GGD_MSD_BINS - 1)], 1u);
+      if (fold.msd) {   // two-launch sort: the bucket inside the key window (never shared by a wave) and the top byte (almost always)
+        if (visible) {
+          const uint32_t bkt = (key - fold.msd_lo) >> fold.msd_shift;     // (a key below the window wraps to a huge value)
+          atomicAdd(&s_hist[min(bkt, (uint32_t)(GGD_MSD_BINS - 1))], 1u);
+          if (bkt > (uint32_t)(GGD_MSD_BINS - 1)) atomicAdd(&s_red[16], 1u);   // outside: the frame will be rendered again
+        }
         const uint32_t d = key >> 24;
         const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, leader);
         if (__ballot(visible && d != d0) == 0ull) {
@@ -258,9 +263,16 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
       atomicAdd(&s_rowdiff[rect_rows >> 16], -1);
     }
     uint32_t tsum = ntiles;
+    // kept-key range of the frame (for the NEXT frames' two-launch-sort window): ~min and max, so that both reduce -- and
+    // accumulate in the zeroed control block -- as maxima
+    uint32_t nmin = visible ? ~key : 0u, kmax = visible ? key : 0u;
 #pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) tsum += __shfl_xor(tsum, sh, 64);
-    if (lane == 0) { s_red[wv] = tsum; s_red[4 + wv] = (uint32_t)__popcll(act); }
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+      tsum += __shfl_xor(tsum, sh, 64);
+      nmin = max(nmin, (uint32_t)__shfl_xor((int)nmin, sh, 64));
+      kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, sh, 64));
+    }
+    if (lane == 0) { s_red[wv] = tsum; s_red[4 + wv] = (uint32_t)__popcll(act); s_red[8 + wv] = nmin; s_red[12 + wv] = kmax; }
     __syncthreads();
     uint32_t* hist = fold.ctl + (blockIdx.x % GGD_FOLD_REPS) * GGD_FOLD_REP_STRIDE;
     const int used = fold.msd ? GGD_FOLD_REP_STRIDE : 4 * 256;
@@ -274,8 +286,21 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
       for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(c, d, 64); if (lane >= d) c += o; }
       if (c) atomicAdd(&fold.ctl[GGD_FOLD_ROWTOT + (blockIdx.x % GGD_FOLD_REPS) * 64 + lane], (uint32_t)c);
     }
-    if (threadIdx.x == 0)
-      fold.wg_info[blockIdx.x] = make_uint2(s_red[0] + s_red[1] + s_red[2] + s_red[3], s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+    if (threadIdx.x == 0) {
+      const uint32_t kept = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+      fold.wg_info[blockIdx.x] = make_uint2(s_red[0] + s_red[1] + s_red[2] + s_red[3], kept);
+      if (kept) {
+        uint32_t* mm = fold.ctl + GGD_FOLD_MINMAX + GGD_FOLD_MINMAX_STRIDE * (blockIdx.x % GGD_FOLD_REPS);
+        const uint32_t nmin_wg = max(max(s_red[8], s_red[9]), max(s_red[10], s_red[11]));
+        const uint32_t kmax_wg = max(max(s_red[12], s_red[13]), max(s_red[14], s_red[15]));
+        // (the running values only grow: a stale read can only cause a redundant atomic, never a missed one)
+        const uint32_t cur0 = __hip_atomic_load(mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t cur1 = __hip_atomic_load(mm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nmin_wg > cur0) atomicMax(mm, nmin_wg);
+        if (kmax_wg > cur1) atomicMax(mm + 1, kmax_wg);
+      }
+      if (s_red[16]) atomicAdd(&fold.ctl[GGD_FOLD_OUTSIDE], s_red[16]);
+    }
   }
 }
 

@@ -233,11 +233,13 @@ enum {
   GGD_OPT_FOLD = 4,       /* single-call forward on the tile-binning path: 1 (default) = the per-Gaussian kernel also builds the
                              depth sort's digit histograms and the first step of the offsets scan (no histogram launch);
                              0 = separate histogram launch.  Results are identical. */
-  GGD_OPT_MSD_SORT = 5,   /* 1 (default): once the depth keys' top byte has been constant for 8 frames, the depth sort of the
-                             single-call forward runs as TWO launches (one partition by key bits 14..23 without any dependency
-                             between tiles + an in-LDS finish per bucket) instead of three onesweep passes; verified by every
-                             frame's own histograms, a frame it does not hold for is re-rendered by the ordinary path.
-                             0 = never.  Results are identical. */
+  GGD_OPT_MSD_SORT = 5,   /* 1 (default): once the kept depth keys' ranges of 8 single-call frames are known, the depth sort of the
+                             single-call forward runs as TWO launches over a speculated key window fitted to those ranges (one
+                             partition by (key - window start) >> shift without any dependency between tiles + an in-LDS finish
+                             per bucket) instead of three or four onesweep passes; verified by every frame's own front end (no
+                             kept key outside the window, no bucket above the finish kernel's capacity), a frame it does not hold
+                             for is re-rendered by the ordinary path and its range joins the window.  0 = never.  Results are
+                             identical.  Setting this option or GGD_OPT_FOLD (to any value) restarts the speculation state. */
   GGD_OPT_COUNT
 };
 int ggd_set_option(ggd_ctx* ctx, int option, int value);

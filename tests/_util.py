@@ -259,3 +259,30 @@ def check_gradients(d, got: dict, ref: dict, budget: dict, fragile, kappa=KAPPA,
                                median_tol=float(np.median(tol))))
         worst = max(worst, float(ratio.max(initial=0.0)))
     return worst
+
+
+def msd_window(ranges, buckets=512):
+    """The two-launch depth sort's key window (csrc/ggd_capi.hip::msd_fit_window) for frames whose kept depth keys (uint32 views of
+    the fp32 depths) span `ranges` = [(min, max), ...]: returns (lo, shift), or None when the window is too wide for the two
+    finishing passes.  A frame's bucket sizes are then np.bincount(np.minimum((keys - lo) >> shift, 1023))."""
+    lo, hi = min(int(r[0]) for r in ranges), max(int(r[1]) for r in ranges)
+    margin = ((hi - lo) >> 3) + 4096
+    wlo, whi = max(0, lo - margin), min(0xfffffffe, hi + margin)
+    span, shift = whi - wlo, 0
+    while (span >> shift) >= buckets:
+        shift += 1
+    return (wlo, shift) if shift <= 16 else None
+
+
+def depth_keys(o):
+    """uint32 depth keys of the oracle forward's visible Gaussians (int64 array)"""
+    return o["depths"][o["radii"] > 0].astype(np.float32).view(np.uint32).astype(np.int64)
+
+
+def msd_bucket_sizes(o, window=None):
+    """bucket sizes the two-launch sort would see for the oracle frame `o` over `window` (default: fitted to the frame itself)"""
+    dk = depth_keys(o)
+    w = window if window is not None else msd_window([(dk.min(), dk.max())])
+    if w is None:
+        return None
+    return np.bincount(np.minimum((dk - w[0]) >> w[1], 1023), minlength=1024)

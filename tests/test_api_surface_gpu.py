@@ -243,3 +243,37 @@ def test_blend_statistics_do_not_change_the_image_and_account_for_every_wave(nat
     assert int(tl[:, 2].sum()) == 4 * ref[0]
     assert (tl[:, 3] <= tl[:, 2]).all()
     assert int(tl[:, 3].sum()) == st["visited"]
+
+
+def test_forward_calls_are_refused_while_a_frame_is_pending(native_lib):
+    """Between ggd_forward_enqueue and ggd_forward_collect the frame's verification state (was the speculated sort form valid?)
+    lives on the context: any other forward on that context is refused with GGD_E_INVALID instead of silently dropping it
+    (ADVICE r05); after the collect the context works as before and the collected frame is the ordinary path's frame."""
+    import ctypes as C
+    from gaussian_gan_decoder_amd import _capi, rasterizer as R
+    from _util import scene_inputs, device_args, same_frame
+    dev = torch.device("cuda:0")
+    d = scene_inputs(P=8000, size=128, lsm=-4.5, seed=77)
+    args = device_args(d, dev)
+    ref = R.rasterize_gaussians_native(*args)
+    R.rasterize_gaussians_native(*args)                       # (capacity hint for the shape)
+    pipe = R.FramePipeline(dev, slots=1)
+    assert pipe.submit(*args) is None                          # first frame of the slot's context: rendered synchronously
+    assert pipe.submit(*args) is not None                      # collected the first, enqueued the second: now pending
+    slot = pipe.slots[0]
+    assert slot["pending"] is not None and "result" not in slot["pending"]
+    with torch.cuda.stream(slot["stream"]):
+        ctx, handle = _capi.context_and_stream(dev)
+        with pytest.raises(_capi.RasterError, match="pending"):
+            R.rasterize_gaussians_native(*args)                # ggd_forward on the slot's context
+        prm = slot["pending"]["prm"]
+        Rn = C.c_int64(0)
+        rc = ctx.lib.ggd_forward_geometry(ctx.handle, C.c_void_p(handle), C.byref(prm), *([None] * 7), None, None, C.byref(Rn))
+        assert rc == -1 and b"pending" in ctx.lib.ggd_last_error(ctx.handle)
+    (res,) = pipe.drain()
+    res[-1].synchronize()
+    assert same_frame(res, ref)
+    with torch.cuda.stream(slot["stream"]):
+        again = R.rasterize_gaussians_native(*args)
+    torch.cuda.synchronize()
+    assert same_frame(again, ref)

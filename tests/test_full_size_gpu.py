@@ -173,6 +173,7 @@ def _shipped_context(dev):
     ctx = _capi.context_and_stream(dev)[0]
     ctx.set_option(_capi.OPT_BINNING, 1)
     assert ctx.get_option(_capi.OPT_FOLD) == 1 and ctx.get_option(_capi.OPT_MSD_SORT) == 1 and ctx.get_option(_capi.OPT_EXP_MODE) == 3
+    ctx.set_option(_capi.OPT_MSD_SORT, 1)      # same value: restarts the cross-frame speculation state (a pause left by another test)
     return ctx
 
 
@@ -285,3 +286,16 @@ def test_many_gaussians_beyond_the_resident_tile_count(native_lib):
     n_sort = run_native(d, debug=False, binning=0)       # the radix-sort path builds the same lists
     np.testing.assert_array_equal(n_sort["point_list"], n["point_list"])
     np.testing.assert_array_equal(n_sort["ranges"], n["ranges"])
+    # ... and the two-launch depth sort with MORE THAN 1024 sort tiles (1123 here): the second round of the finish kernel's piece
+    # table and the upper half of its binary search over the pieces only run beyond 4.19 M Gaussians
+    from gaussian_gan_decoder_amd import _capi, rasterizer as R_
+    dev = torch.device("cuda:0")
+    ctx = _shipped_context(dev)
+    ctx.set_option(_capi.OPT_MSD_SORT, 1)
+    args = device_args(d, dev)
+    ref = (n["num_rendered"], n["color"], n["radii"], n["geom"], n["binning"], n["img"])
+    m0, r0 = ctx.get_option(_capi.STAT_MSD_FRAMES), ctx.get_option(_capi.STAT_SORT_RERUNS)
+    for i in range(11):
+        res = R_.rasterize_gaussians_native(*args)
+        assert same_frame(res, ref), f"single-call frame {i} differs"
+    assert ctx.get_option(_capi.STAT_MSD_FRAMES) >= m0 + 2 and ctx.get_option(_capi.STAT_SORT_RERUNS) == r0
