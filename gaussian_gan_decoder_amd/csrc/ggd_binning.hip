@@ -225,21 +225,14 @@ __global__ __launch_bounds__(RS_THREADS) void sort_global_hist_kernel(const KeyT
   if (SKIP && n_valid && my_valid) atomicAdd(n_valid, my_valid);
 }
 
-// The kept keys' range of this frame (GGD_FOLD_MINMAX replicas, filled by the preprocess kernel): reduced by the first wave of the
-// workgroup that delivers num_rendered and stored -- BEFORE the tagged word's release store, by the same thread -- into
-// d_total[3..5] and the pinned words 4..6: {min key, max key, flags (bit 0: top byte constant, 1: no key outside the two-launch
-// sort's window, 2: no bucket above its capacity)}.  The host fits the next frames' window to these ranges.
-__device__ __forceinline__ void fold_publish_range(const ggd_scan_piggy& pg, uint32_t flags) {
-  if (threadIdx.x >= 64) return;
-  const int lane = threadIdx.x;
-  uint32_t v = lane < 2 * GGD_FOLD_REPS ? pg.fold_hist[GGD_FOLD_MINMAX + (lane >> 1) * GGD_FOLD_MINMAX_STRIDE + (lane & 1)] : 0u;   // even lanes ~min, odd lanes max
-#pragma unroll
-  for (int sh = 2; sh < 2 * GGD_FOLD_REPS; sh <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, sh, 64));
-  const uint32_t nmin = (uint32_t)__shfl((int)v, 0, 64), kmax = (uint32_t)__shfl((int)v, 1, 64);
-  if (lane == 0) {
-    if (pg.d_total) { pg.d_total[3] = ~nmin; pg.d_total[4] = kmax; pg.d_total[5] = flags; }
-    if (pg.h_total) { pg.h_total[4] = ~nmin; pg.h_total[5] = kmax; pg.h_total[6] = flags; }
-  }
+// The kept keys' range of this frame (reduced from the preprocess workgroups' records by scan_info_block), stored -- BEFORE the
+// tagged word's release store, by the same thread -- into d_total[3..5] and the pinned words 4..6: {min key, max key, flags (bit 0:
+// top byte constant, 1: no key outside the two-launch sort's window, 2: no bucket above its capacity)}.  The host fits the next
+// frames' window to these ranges.
+__device__ __forceinline__ void fold_publish_range(const ggd_scan_piggy& pg, uint32_t flags, uint32_t nmin, uint32_t kmax) {
+  if (threadIdx.x != 0) return;
+  if (pg.d_total) { pg.d_total[3] = ~nmin; pg.d_total[4] = kmax; pg.d_total[5] = flags; }
+  if (pg.h_total) { pg.h_total[4] = ~nmin; pg.h_total[5] = kmax; pg.h_total[6] = flags; }
 }
 
 // COMPACT (depth sort): pass 0 (IOTA) drops keys equal to ~0 -- they are neither ranked nor written -- and every later
@@ -259,7 +252,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
   __shared__ uint32_t s_cnt[4][RS_BINS];   // per-wave running digit counts -> per-wave scatter bases
   if ((int)blockIdx.x >= ntiles) {   // appended workgroups: steps 2 / 3 of the offsets scan (see ggd_scan_piggy)
     if (piggy_role == 2 && pg.wg_info) {
-      const uint2 tv = scan_info_block(pg.wg_info, pg.n_info, pg.block_sums, pg.n_valid, pg.d_total, pg.h_total, &s_cnt[0][0]);
+      const uint4 tv = scan_info_block(pg.wg_info, pg.n_info, pg.block_sums, pg.n_valid, pg.d_total, pg.h_total, &s_cnt[0][0]);
       int flat = 0;
       if (pg.fold_hist) {   // passes 1 .. 3 then read ONE histogram (pass 0's tiles, running beside us, read their own 256 bins
                             // of every replica: reading all replicas cost each pass ~2 us)
@@ -275,7 +268,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_onesweep_kernel(
           pg.fold_hist[p * RS_BINS + threadIdx.x] = acc[p - 1];
         }
         flat = __syncthreads_or(acc[2] == tv.y);   // the top digit of every kept key is the same (also: nothing kept)
-        fold_publish_range(pg, flat ? 1u : 0u);
+        fold_publish_range(pg, flat ? 1u : 0u, tv.z, tv.w);
       }
       if (threadIdx.x == 0) {
         if (pg.spec_flat && pg.flat_flag) *pg.flat_flag = 1u;
@@ -471,15 +464,22 @@ static_assert((1 << MSD_DIGIT_BITS) == GGD_MSD_BINS && GGD_MSD_BINS % (4 * RS_TH
 // verdict on the speculation: no kept key outside the window and no bucket above GGD_MSD_CAP (bit 62 of the tagged word; bit 63
 // keeps saying "top byte constant", for the three-pass form's streak)
 __device__ __forceinline__ void msd_piggy_block(const ggd_scan_piggy& pg, uint32_t* lds) {
-  const uint2 tv = scan_info_block(pg.wg_info, pg.n_info, pg.block_sums, pg.n_valid, pg.d_total, pg.h_total, lds);
   constexpr int NS = GGD_FOLD_REP_STRIDE / 256;   // 256-word slabs per replica: the bucket histogram, then the top byte's
+  // (the replicas' words and the outside-the-window count are requested before the scan, all at once: nothing here depends on it)
+  uint32_t rep[GGD_FOLD_REPS][NS];
+#pragma unroll
+  for (int r = 0; r < GGD_FOLD_REPS; ++r)
+#pragma unroll
+    for (int q = 0; q < NS; ++q) rep[r][q] = pg.fold_hist[r * GGD_FOLD_REP_STRIDE + q * 256 + threadIdx.x];
+  const uint32_t outside = pg.fold_hist[GGD_FOLD_OUTSIDE];
+  const uint4 tv = scan_info_block(pg.wg_info, pg.n_info, pg.block_sums, pg.n_valid, pg.d_total, pg.h_total, lds);
   uint32_t acc[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) acc[q] = 0u;
-#pragma unroll 4
+#pragma unroll
   for (int r = 0; r < GGD_FOLD_REPS; ++r) {
 #pragma unroll
-    for (int q = 0; q < NS; ++q) acc[q] += pg.fold_hist[r * GGD_FOLD_REP_STRIDE + q * 256 + threadIdx.x];
+    for (int q = 0; q < NS; ++q) acc[q] += rep[r][q];
   }
   bool over = false;
 #pragma unroll
@@ -489,9 +489,9 @@ __device__ __forceinline__ void msd_piggy_block(const ggd_scan_piggy& pg, uint32
   }
   const int flat = __syncthreads_or(acc[NS - 1] == tv.y);   // (also: nothing kept)
   const int big = __syncthreads_or(over);
-  const bool inside = pg.fold_hist[GGD_FOLD_OUTSIDE] == 0u;
+  const bool inside = outside == 0u;
   const unsigned long long ok = (inside && !big) ? 1ull : 0ull;
-  fold_publish_range(pg, (flat ? 1u : 0u) | (inside ? 2u : 0u) | (big ? 0u : 4u));
+  fold_publish_range(pg, (flat ? 1u : 0u) | (inside ? 2u : 0u) | (big ? 0u : 4u), tv.z, tv.w);
   if (threadIdx.x == 0) {
     if (pg.d_total) pg.d_total[2] = (uint32_t)(flat ? 1u : 0u) | ((uint32_t)ok << 1);
     if (pg.h_tagged)

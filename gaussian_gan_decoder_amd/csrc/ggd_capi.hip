@@ -326,10 +326,10 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
   ctx->msd_frame = false;
   if (ride && ctx->opt[GGD_OPT_FOLD] != 0) {
     const int nwg = (prm->P + 255) / 256;
-    if (ctx->scan_sums_cap < 3 * nwg + 64) {   // [exclusive prefixes: nwg words | {sum, kept}: nwg uint2]
+    if (ctx->scan_sums_cap < 5 * nwg + 64) {   // [exclusive prefixes: nwg words | {sum, kept, ~min key, max key}: nwg uint4]
       if (ctx->scan_sums) (void)hipFree(ctx->scan_sums);
       ctx->scan_sums = nullptr; ctx->scan_sums_cap = 0;
-      const int cap = 3 * (nwg + nwg / 2) + 64;
+      const int cap = 5 * (nwg + nwg / 2) + 64;
       GGD_HIP(hipMalloc((void**)&ctx->scan_sums, (size_t)cap * sizeof(uint32_t)));
       ctx->scan_sums_cap = cap;
     }
@@ -358,7 +358,7 @@ static int geometry_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, c
     fold.ctl = ctx->foldctl[cur];
     fold.clear = ctx->foldctl[oth];
     fold.clear_words = (uint32_t)ctx->foldctl_dirty[oth];
-    fold.wg_info = reinterpret_cast<uint2*>(ctx->scan_sums + (((size_t)nwg + 1) & ~(size_t)1));
+    fold.wg_info = reinterpret_cast<uint4*>(ctx->scan_sums + (((size_t)nwg + 3) & ~(size_t)3));
     fold.rows = ((prm->width + 15) / 16 <= 64 && (prm->height + 15) / 16 <= 64) ? 1 : 0;
     // two-launch depth sort: speculated once the key ranges of GGD_FLAT_STREAK folded frames are known (render_enqueue: folded,
     // tile binning, speculative), decided HERE because it selects the histograms this launch builds
@@ -553,7 +553,7 @@ static int render_enqueue(ggd_ctx* ctx, void* stream, const ggd_params* prm, con
         if (folded) {
           const int nwg = (prm->P + 255) / 256;
           fold.ctl = ctx->foldctl[ctx->fold_cur ^ 1];   // (fold_cur already points at the next frame's block)
-          pg.wg_info = reinterpret_cast<const uint2*>(ctx->scan_sums + (((size_t)nwg + 1) & ~(size_t)1));
+          pg.wg_info = reinterpret_cast<const uint4*>(ctx->scan_sums + (((size_t)nwg + 3) & ~(size_t)3));
           pg.n_info = nwg;
           pg.sum_stride = 8;                            // 2048-element scan blocks over 256-point workgroup prefixes
         }

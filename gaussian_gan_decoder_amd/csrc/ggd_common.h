@@ -110,7 +110,7 @@ struct ggd_scan_piggy {
   uint32_t tag = 0;                         // polls it instead of waiting on an event (an event record between two kernels
                                             // costs the GPU a ~6 us bubble)
   // folded front end (ggd_fold): step 1 was done by the preprocess workgroups (256 points each) -- step 2 scans their sums
-  const uint2* wg_info = nullptr;           // [n_info] {sum of tiles_touched, kept depth keys} per preprocess workgroup
+  const uint4* wg_info = nullptr;           // [n_info] {sum of tiles_touched, kept depth keys, ~min kept key, max kept key} per preprocess workgroup
   int n_info = 0;
   uint32_t* n_valid = nullptr;              // receives the number of kept keys (sum of wg_info[].y)
   int sum_stride = 1;                       // block_sums entries per scan block of step 3 (8 with wg_info: 2048 / 256)
@@ -158,17 +158,16 @@ constexpr int GGD_FOLD_REP_STRIDE = GGD_MSD_BINS + 256;   // ordinary frames: th
 constexpr int GGD_FOLD_OUTSIDE = GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE + 16;
 constexpr int GGD_FOLD_ROWTOT = GGD_FOLD_REPS * GGD_FOLD_REP_STRIDE + 64;   // REPS x 64 words: entries per tile ROW (grids of <= 64
                                                                            // rows), for the row binning's first level
-// {~min, max} of the kept keys (atomicMax both: the block starts zeroed), one replica per 64-byte LINE: atomics on one line
-// serialise at ~11 ns each -- with the 16 replicas packed into two lines the 7800 atomics of a 1 M-point frame cost the
-// preprocess kernel 30 us (round 6, first form) -- and a workgroup only issues them when its value beats the one it reads first
-constexpr int GGD_FOLD_MINMAX = GGD_FOLD_ROWTOT + GGD_FOLD_REPS * 64;
-constexpr int GGD_FOLD_MINMAX_STRIDE = 16;
-constexpr int GGD_FOLD_HEAD = GGD_FOLD_MINMAX + GGD_FOLD_REPS * GGD_FOLD_MINMAX_STRIDE;        // words in front of the status words
+// (The kept keys' range of a frame -- what the two-launch sort's window is fitted to -- travels with the per-workgroup sums in
+// wg_info, as plain stores.  Round 6's first forms kept {~min, max} replicas here, updated with atomicMax: 16 replicas packed into
+// two 64-byte lines cost the preprocess kernel + 30 us (atomics on one line serialise at ~11 ns), one line per replica behind a
+// read-and-compare still + 10 us: a device-scope load + atomic at the END of every workgroup adds 2 - 4 us to its ~8 us lifetime.)
+constexpr int GGD_FOLD_HEAD = GGD_FOLD_ROWTOT + GGD_FOLD_REPS * 64;        // words in front of the status words
 struct ggd_fold {
   uint32_t* ctl = nullptr;        // this frame's control block (clean)
   uint32_t* clear = nullptr;      // the other block ...
   uint32_t clear_words = 0;       // ... and how much of it the preprocess clears for the next frame
-  uint2* wg_info = nullptr;       // [ceil(P / 256)]
+  uint4* wg_info = nullptr;       // [ceil(P / 256)] {sum of tiles_touched, kept keys, ~min kept key, max kept key}
   int rows = 0;                   // != 0: also count the Gaussians per tile row (the grid has <= 64 rows)
   int msd = 0;                    // != 0: histograms of the two-launch sort (1024 buckets of the key window, top byte) instead of the four bytes
   uint32_t msd_lo = 0;            // bucket of a kept key = min((key - msd_lo) >> msd_shift, 1023); a key for which the unclamped

@@ -288,17 +288,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     }
     if (threadIdx.x == 0) {
       const uint32_t kept = s_red[4] + s_red[5] + s_red[6] + s_red[7];
-      fold.wg_info[blockIdx.x] = make_uint2(s_red[0] + s_red[1] + s_red[2] + s_red[3], kept);
-      if (kept) {
-        uint32_t* mm = fold.ctl + GGD_FOLD_MINMAX + GGD_FOLD_MINMAX_STRIDE * (blockIdx.x % GGD_FOLD_REPS);
-        const uint32_t nmin_wg = max(max(s_red[8], s_red[9]), max(s_red[10], s_red[11]));
-        const uint32_t kmax_wg = max(max(s_red[12], s_red[13]), max(s_red[14], s_red[15]));
-        // (the running values only grow: a stale read can only cause a redundant atomic, never a missed one)
-        const uint32_t cur0 = __hip_atomic_load(mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t cur1 = __hip_atomic_load(mm + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (nmin_wg > cur0) atomicMax(mm, nmin_wg);
-        if (kmax_wg > cur1) atomicMax(mm + 1, kmax_wg);
-      }
+      fold.wg_info[blockIdx.x] = make_uint4(s_red[0] + s_red[1] + s_red[2] + s_red[3], kept,
+                                            max(max(s_red[8], s_red[9]), max(s_red[10], s_red[11])),
+                                            max(max(s_red[12], s_red[13]), max(s_red[14], s_red[15])));
       if (s_red[16]) atomicAdd(&fold.ctl[GGD_FOLD_OUTSIDE], s_red[16]);
     }
   }

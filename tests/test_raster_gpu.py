@@ -568,7 +568,7 @@ def test_two_launch_sort_when_every_key_of_a_sort_tile_is_kept(native_lib):
     assert_blend_matches(n, o)
 
 
-@pytest.mark.parametrize("squeeze,lo,hi", [(0.004, 6000, 8000), (0.002, 8000, 12288)])
+@pytest.mark.parametrize("squeeze,lo,hi", [(0.008, 6000, 8000), (0.002, 8000, 12288)])
 def test_two_launch_sort_with_dense_buckets(native_lib, squeeze, lo, hi):
     """The finish kernel's two larger forms: a bucket close to what it exchanges through LDS (8 elements per thread), and one
     above that but inside GGD_MSD_CAP, which exchanges through its slice of the output arrays.  40 000 of 60 000 Gaussians are
