@@ -19,7 +19,7 @@ EXPORTS = [
     "ggd_img_layout", "ggd_sort_bits", "ggd_create", "ggd_destroy", "ggd_last_error", "ggd_version",
     "ggd_forward_geometry", "ggd_forward_render", "ggd_forward", "ggd_forward_enqueue", "ggd_forward_collect", "ggd_forward_can_speculate", "ggd_backward", "ggd_mark_visible", "ggd_debug_unsorted",
     "ggd_triplane_forward", "ggd_triplane_backward", "ggd_trigrid_forward", "ggd_trigrid_backward", "ggd_planes_gather", "ggd_planes_scatter", "ggd_surface_tmp_bytes", "ggd_surface_sample", "ggd_attrs_split", "ggd_attrs_merge", "ggd_decoder_packed_bytes", "ggd_decoder_pack", "ggd_decoder_forward", "ggd_decoder_zbuf_bytes", "ggd_decoder_packed_t_bytes",
-    "ggd_decoder_forward_train", "ggd_decoder_backward", "ggd_decoder_wgrad_floats", "ggd_decoder_wgrad", "ggd_decoder_backward_wgrad", "ggd_decoder_packed_hl_bytes", "ggd_decoder_packed_t_hl_bytes", "ggd_decoder_dzbuf_hl_bytes", "ggd_decoder_pack_hl", "ggd_decoder_forward_hl", "ggd_decoder_backward_wgrad_hl", "ggd_image_loss_tmp_bytes", "ggd_image_loss", "ggd_set_option", "ggd_get_option", "ggd_blend_stats", "ggd_blend_timeline", "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
+    "ggd_decoder_forward_train", "ggd_decoder_backward", "ggd_decoder_wgrad_floats", "ggd_decoder_wgrad", "ggd_decoder_backward_wgrad", "ggd_decoder_packed_hl_bytes", "ggd_decoder_packed_t_hl_bytes", "ggd_decoder_dzbuf_hl_bytes", "ggd_decoder_pack_hl", "ggd_decoder_forward_hl", "ggd_decoder_backward_wgrad_hl", "ggd_image_loss_tmp_bytes", "ggd_image_loss", "ggd_set_option", "ggd_get_option", "ggd_blend_stats", "ggd_blend_backward_stats", "ggd_blend_timeline", "ggd_set_profiling", "ggd_stage_count", "ggd_stage_name", "ggd_stage_times",
 ]
 
 
@@ -116,6 +116,7 @@ def load():
         lib.ggd_set_option.argtypes = [vp, C.c_int, C.c_int]
         lib.ggd_get_option.argtypes = [vp, C.c_int]
         lib.ggd_blend_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_ulonglong)]
+        lib.ggd_blend_backward_stats.argtypes = [vp, C.POINTER(C.c_ulonglong)]
         lib.ggd_blend_timeline.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
         lib.ggd_set_profiling.argtypes = [vp, C.c_int]
         lib.ggd_stage_name.restype = C.c_char_p; lib.ggd_stage_name.argtypes = [C.c_int]
@@ -160,6 +161,12 @@ class Context:
         out = (C.c_ulonglong * 6)()
         self.check(self.lib.ggd_blend_stats(self.handle, int(enable), out))
         return dict(zip(("visited", "culled", "lanes", "pixels", "listed", "culled_in_loop"), [int(v) for v in out]))
+
+    def blend_backward_stats(self):
+        """Work counters of the backward blends (quarter form) since blend_stats(True); call before blend_stats(False)."""
+        out = (C.c_ulonglong * 8)()
+        self.check(self.lib.ggd_blend_backward_stats(self.handle, out))
+        return dict(zip(("walked", "staged", "needed", "blended", "live_lanes", "atomic_spans", "rounds", "waves"), [int(v) for v in out]))
 
     def blend_timeline(self, waves: int):
         """[waves, 4] int64 array: start tick, end tick (100 MHz), list length, entries gathered -- of the forward blend that

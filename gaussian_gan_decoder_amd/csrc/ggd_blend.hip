@@ -782,11 +782,17 @@ __global__ __launch_bounds__(256) void blend_backward_tile_kernel(
 // a tile costs k coalesced atomic spans instead of one; in exchange the four quarters never wait for each other (the tile
 // form spent 13 % / 28 % of its time in the per-round lock step: cube / shell), and the four quarters of a tile are placed in
 // consecutive dispatch slots of one XCD like the forward's.
-template <int EXP_MODE, bool CULL>
+// STATS (ggd_blend_stats, debug): per-wave work counters added to stats[GGD_STATS_BWD ..] at the wave's end -- list entries the
+// wave walks (its share of the tile's list up to its last contributor), records staged after the pre-cull, staged records some
+// pixel still needed (`need`), records at least one pixel actually blended (`live`: a 9-sum reduction + a parked row each),
+// the live lanes of those, rows flushed (= 36-byte atomic spans), gather rounds.
+template <int EXP_MODE, bool CULL, bool STATS = false>
 __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
     int W, int H, int gx, int gy, const ggd_splat* __restrict__ splat, const uint32_t* __restrict__ list,
     const uint32_t* __restrict__ ranges, const float* __restrict__ bg, const float* __restrict__ final_T,
-    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ grad_acc) {
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix, float* __restrict__ grad_acc,
+    unsigned long long* __restrict__ stats = nullptr) {
+  uint32_t st_staged = 0, st_need = 0, st_live = 0, st_lanes = 0, st_spans = 0, st_rounds = 0;
   __shared__ float4 s_rec[64 * 3];
   // [touched record, in processing order][9 sums | staging slot] (5632 B of LDS per wave with s_rec); ONE buffer: a round's
   // rows are flushed at the top of the next round, before that round's first row is written (LDS operations of a wave
@@ -903,6 +909,7 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
     __builtin_amdgcn_wave_barrier();                     // before the new loads are issued
     const uint64_t kept = __ballot(keep);
     const int nk = __popcll(kept), n8 = (nk + 7) & ~7;
+    if (STATS) { st_staged += (uint32_t)nk; st_rounds += 1; st_spans += (uint32_t)prev_cnt; }
     if (keep) {  // compacted, order preserved
       const int slot = __popcll(kept & lt_mask);
       s_rec[slot * 3 + 0] = r0; s_rec[slot * 3 + 1] = r1; s_rec[slot * 3 + 2] = r2;
@@ -936,10 +943,12 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
         const float pw = __builtin_fmaf(__builtin_fmaf(a.z, dx, nBdy), dx, hCdy2);
         const uint64_t need = __ballot(pos0 < lastn) & __ballot(pw >= b.y);
         if (need == 0ull) continue;
+        if (STATS) st_need += 1;
         const float col[3] = {c4.z, c4.x, c4.y};                     // r | g, b
         float s[8], sop;                                             // colour r g b | conic A B C | mean sums x y ; opacity
         const uint64_t live = bwd_update<EXP_MODE>(st, pw, dx, dy, need, b.z, col, s, sop);
         if (live != 0ull) {   // wave-uniform: somebody in this wave saw the Gaussian
+          if (STATS) { st_live += 1; st_lanes += (uint32_t)__popcll(live); }
           const float tot = wave_reduce9_swap(s, sop, 0x2222222222222222ull);
           // writers: lanes 0,4,8,12 | 32,36,40,44 (component from the table above), lane 1 the opacity sum; lane 2 the
           // record's slot in the staging area
@@ -954,6 +963,17 @@ __global__ __launch_bounds__(64) void blend_backward_quarter_kernel(
   }
   __builtin_amdgcn_wave_barrier();
   flush(prev_cnt);
+  if (STATS && lane == 0 && stats) {
+    unsigned long long* o = stats + GGD_STATS_BWD;
+    atomicAdd(o + 0, (unsigned long long)maxn);
+    atomicAdd(o + 1, (unsigned long long)st_staged);
+    atomicAdd(o + 2, (unsigned long long)st_need);
+    atomicAdd(o + 3, (unsigned long long)st_live);
+    atomicAdd(o + 4, (unsigned long long)st_lanes);
+    atomicAdd(o + 5, (unsigned long long)(st_spans + (uint32_t)prev_cnt));
+    atomicAdd(o + 6, (unsigned long long)st_rounds);
+    atomicAdd(o + 7, 1ull);
+  }
 }
 
 }  // namespace
@@ -1003,8 +1023,16 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
   static const int lds_pad = getenv("GGD_BLEND_BWD_LDS_PAD") ? atoi(getenv("GGD_BLEND_BWD_LDS_PAD")) : 0;   // experiment
   if (split == 4) {
 #define GGD_LAUNCH_BQ(EM, CU)                                                                                             \
-    hipLaunchKernelGGL((blend_backward_quarter_kernel<EM, CU>), dim3(4 * T), dim3(64), lds_pad, s, prm.width, prm.height, gx, \
-                       gy, splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc)
+    do {                                                                                                                  \
+      if (ctx->blend_stats)                                                                                               \
+        hipLaunchKernelGGL((blend_backward_quarter_kernel<EM, CU, true>), dim3(4 * T), dim3(64), lds_pad, s, prm.width,   \
+                           prm.height, gx, gy, splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc,        \
+                           ctx->blend_stats);                                                                             \
+      else                                                                                                                \
+        hipLaunchKernelGGL((blend_backward_quarter_kernel<EM, CU>), dim3(4 * T), dim3(64), lds_pad, s, prm.width,         \
+                           prm.height, gx, gy, splat, list, ranges, prm.bg, final_T, n_contrib, dL_dpix, grad_acc,        \
+                           (unsigned long long*)nullptr);                                                                 \
+    } while (0)
     if (cull) {
       if (em == 0) GGD_LAUNCH_BQ(0, true); else if (em == 1) GGD_LAUNCH_BQ(1, true); else if (em == 2) GGD_LAUNCH_BQ(2, true); else GGD_LAUNCH_BQ(3, true);
     } else {

@@ -197,6 +197,13 @@ extern "C" int ggd_blend_stats(ggd_ctx* ctx, int enable, unsigned long long* out
   }
   return GGD_OK;
 }
+extern "C" int ggd_blend_backward_stats(ggd_ctx* ctx, unsigned long long* out) {
+  if (!ctx || !out) return GGD_E_INVALID;
+  if (!ctx->stats_buf) return ggd_fail(ctx, GGD_E_INVALID, "ggd_blend_backward_stats: statistics were never enabled (ggd_blend_stats)");
+  GGD_HIP(hipDeviceSynchronize());
+  GGD_HIP(hipMemcpy(out, ctx->stats_buf + GGD_STATS_BWD, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return GGD_OK;
+}
 extern "C" int ggd_blend_timeline(ggd_ctx* ctx, unsigned long long* out, int waves) {
   if (!ctx || !out || waves < 0 || waves > GGD_STATS_MAX_WAVES) return GGD_E_INVALID;
   if (!ctx->stats_buf) return ggd_fail(ctx, GGD_E_INVALID, "ggd_blend_timeline: statistics were never enabled");

@@ -24,7 +24,8 @@ enum { GGD_ATTR_MLP_FWD = 1, GGD_ATTR_MLP_BWD = 2, GGD_ATTR_MLP_WGRAD = 4, GGD_A
 
 // layout of the debug statistics buffer of the forward blend (ggd_blend_stats / ggd_blend_timeline)
 constexpr int GGD_STATS_MODE = 9;            // word: 0 = counters (atomics), 1 = per-wave timeline slots
-constexpr int GGD_STATS_HEAD = 16;           // first timeline slot (3 words per wave: start, end, listed << 32 | gathered)
+constexpr int GGD_STATS_BWD = 16;            // eight counters of the backward blend (quarter form), see blend_backward_quarter_kernel
+constexpr int GGD_STATS_HEAD = 32;           // first timeline slot (3 words per wave: start, end, listed << 32 | gathered)
 constexpr int GGD_STATS_MAX_WAVES = 1 << 17;
 
 // two-launch depth sort (described at ggd_fold below)

@@ -252,6 +252,11 @@ int ggd_set_option(ggd_ctx* ctx, int option, int value);
  * (list length << 32 | list entries gathered before the wave's pixels were all finished).  (The counters are same-address
  * atomics and stretch the kernel; the timeline is one plain store per wave.) */
 int ggd_blend_stats(ggd_ctx* ctx, int enable, unsigned long long* out);
+/* ... and of the backward blends (quarter form) that ran since ggd_blend_stats(ctx, 1, ..) started counting; call BEFORE stopping:
+ * out[0]=list entries walked (sum over quarter waves of the positions up to the wave's last contributor), [1]=records staged after
+ * the pre-cull, [2]=staged records some pixel of the wave still needed, [3]=records at least one pixel blended (one 9-sum wave
+ * reduction each), [4]=live lanes of those, [5]=rows flushed = 36-byte atomic spans, [6]=gather rounds, [7]=waves with work. */
+int ggd_blend_backward_stats(ggd_ctx* ctx, unsigned long long* out);
 int ggd_blend_timeline(ggd_ctx* ctx, unsigned long long* out, int waves);
 int ggd_get_option(ggd_ctx* ctx, int option);
 /* Read-only counters through ggd_get_option (single-call forward with GGD_OPT_FOLD = 1): the depth keys' top byte is constant in
