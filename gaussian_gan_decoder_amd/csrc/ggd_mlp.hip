@@ -47,7 +47,10 @@ constexpr int OFF_W3 = OFF_W2 + HID * ROW2;
 constexpr int OFF_W4 = OFF_W3 + HID * ROW2;
 constexpr int OFF_B = OFF_W4 + 16 * ROW2;          // fp32 biases: b1[128] b2[128] b3[128] b4[16]
 constexpr int HEAD_BYTES = OFF_B + (3 * HID + 16) * 4;  // 87,616 B
-constexpr int MLP_THREADS = 512;
+#ifndef GGD_MLP_THREADS   // (timing experiments: 256 = one wave per SIMD in the 16-bit backward kernel, profiles/REJECTED.md round 6)
+#define GGD_MLP_THREADS 512
+#endif
+constexpr int MLP_THREADS = GGD_MLP_THREADS;
 constexpr int MLP_WAVES = MLP_THREADS / 64;
 // forward kernel: the waves that share one head's weights in LDS (95 KB: one workgroup per CU).  Measured at 1 M points:
 // 512 threads 0.796 ms, 768 (3 waves per SIMD, 150 VGPRs still fit) 0.787 ms, 1024 (128-VGPR cap: spills) 0.827 ms --

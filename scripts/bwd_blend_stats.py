@@ -34,7 +34,8 @@ for (P, S, kind) in [(1000000, 1024, 'cube'), (1000000, 1024, 'shell')]:
     fwd_used = f["visited"] - f["culled"]          # staged records at least one pixel of the quarter wave blended (any != 0)
     print(json.dumps(dict(
         scene=f"{P} Gaussians, {S}x{S}, {kind}", num_rendered=R_, quarter_records=4 * R_,
-        forward=dict(**f, staged=f["visited"], used_by_some_pixel=fwd_used, kernel_us=round(tf * 1e3, 1)),
+        forward=dict(**f, gathered=f["visited"], staged=f["visited"] - f["culled"] + f["culled_in_loop"], used_by_some_pixel=fwd_used,
+                     kernel_us=round(tf * 1e3, 1)),
         backward=dict(**b, kernel_us=round(tb * 1e3, 1),
                       walked_frac_of_quarter_records=round(b["walked"] / (4 * R_), 3),
                       staged_frac_of_walked=round(b["staged"] / max(b["walked"], 1), 3),
@@ -43,7 +44,7 @@ for (P, S, kind) in [(1000000, 1024, 'cube'), (1000000, 1024, 'shell')]:
                       spans_per_blended=round(b["atomic_spans"] / max(b["blended"], 1), 3),
                       walked_per_round=round(b["walked"] / max(b["rounds"], 1), 1),
                       staged_per_round=round(b["staged"] / max(b["rounds"], 1), 1),
-                      ns_per_blended_record_wave=round(tb * 1e6 / max(b["blended"], 1) * 1024 * 8 / 1.0, 1)),
+                      valu_wave_insts_per_blended_record="1.76e8 (PMC, profiles/r05/traffic.json) / blended = %.0f" % (1.76e8 / max(b["blended"], 1)) if kind == "cube" else None),
         survivor_list=dict(entries=fwd_used, bytes=4 * fwd_used,
                            backward_gather_rounds_now=b["rounds"], rounds_with_the_list=math.ceil(fwd_used / 64),
                            note="the backward re-runs gather + pre-cull over `walked` list entries to stage `staged` records; with the forward's "
