@@ -26,7 +26,7 @@ copy_stats("train", "kernel_stats_train.csv")
 copy_stats("train_fp32", "kernel_stats_train_fp32.csv")
 copy_stats("hd", "kernel_stats_hd.csv")
 for f in ("bench.json", "bench_under_rocprof.json", "full_size_errors.txt", "hd_timing.txt", "frame_trace_1M_1024_cube.txt",
-          "frame_trace_1M_1024_shell.txt"):
+          "frame_trace_1M_1024_shell.txt", "backward_blend_counters.txt", "kernel_resources.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 for sub, out in (("pmc", "pmc_summary.txt"), ("pmc_shell", "pmc_summary_shell.txt"), ("pmc_mlp", "pmc_summary_mlp.txt"),

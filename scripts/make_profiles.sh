@@ -10,6 +10,7 @@
 #   pmc_hl/     ... of the reference-precision decoder kernels (forward with z, backward, weight gradients), 2 M points
 #   train_fp32/ kernel trace of the train step with the reference-precision fused decoder
 #   hd/         kernel trace of scripts/hd_timing.py (1080p, 2048^2, 4K: every binning path that applies)
+#   backward_blend_counters.txt, kernel_resources.txt, bench.json (plain `python bench.py`), full_size_errors.txt
 set -u
 TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
@@ -36,6 +37,8 @@ bash scripts/pmc_passes.sh $TAG/pmc_shell scripts/fwd_only.py 1M_1024_shell 14 -
 bash scripts/pmc_passes.sh $TAG/pmc_mlp scripts/mlp_only.py 40 > /dev/null
 bash scripts/pmc_passes.sh $TAG/pmc_hl scripts/hl_only.py 3 > /dev/null
 bash scripts/frame_traces.sh gpurun_out/$TAG > /dev/null 2>&1
+python scripts/bwd_blend_stats.py > gpurun_out/$TAG/backward_blend_counters.txt 2> /dev/null
+python scripts/kernel_resources.py > gpurun_out/$TAG/kernel_resources.txt 2> /dev/null
 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench_plain.err
 python -m pytest tests/test_full_size_gpu.py -m gpu -q -x -s 2>&1 | grep -E "max\||passed|failed|dRGB" > gpurun_out/$TAG/full_size_errors.txt
 echo done
