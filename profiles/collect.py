@@ -2,7 +2,7 @@
 profiles/<tag>/:  kernel_stats.csv, kernel_stats_train.csv, pmc_summary.txt, pmc_summary_shell.txt, pmc_summary_mlp.txt,
 traffic.json (HBM bytes per kernel launch + which kernels make up one forward frame), mlp_pmc.json, bench.json.
 usage: python profiles/collect.py <tag>"""
-import collections, csv, glob, json, os, shutil, subprocess, sys
+import collections, csv, glob, json, os, re, shutil, subprocess, sys
 
 tag = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +11,14 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
+    # (rocprofv3 leaves names with _Float16 / __bf16 parameters mangled: _ZN12_GLOBAL__N_1<len><name>... -- which is how
+    # decoder_forward_kernel never matched and round 5's mlp_pmc.json was not written)
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+    if m:
+        n = int(m.group(1))
+        base = name[m.end():m.end() + n]
+        t = re.match(r"ILb([01])E", name[m.end() + n:])
+        return base + (f"<{'true' if t.group(1) == '1' else 'false'}>" if t else "")
     name = name.split("(anonymous namespace)::")[-1] if "anonymous" in name else name
     return name.split("(")[0].strip()
 

@@ -27,6 +27,7 @@ out += [f"{'frame (%d launches, no gaps)' % len(rows):44s} {tu:7.2f} {tb / 1e6:8
         "The preprocess kernel is the one near its bandwidth roofline (0.55 of the 8 TB/s peak, ~0.85 of what a mixed read / write stream",
         "reaches on this part).  The blend is bound by VALU issue (0.58 of the plain rate; its instructions cost 1.31 units on average,",
         "so ~0.75 of the SIMDs' real rate).  The six kernels between them are chains of dependent memory trips inside short workgroups",
-        "plus ~4.8 us of launch floor per dependent kernel (7 x 4.8 = 34 of the front end's ~100 us)."]
+        "on top of the floor of a dependent launch: 2.6 - 2.8 us for an empty kernel (profiles/r06/launch_floor_probe.txt; 8 launches =",
+        "22 us of the frame), more behind a kernel that leaves dirty lines in the L2s."]
 open(os.path.join(D, "frame_rooflines.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))

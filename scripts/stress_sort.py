@@ -11,6 +11,20 @@ from gaussian_gan_decoder_amd import _capi
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 scenes = [T._sort_case(s)[0] for s in range(24)] + [scene_inputs(P=P, size=S, seed=90 + i, lsm=-5.0) for i, (P, S) in enumerate([(700, 96), (5000, 128), (20000, 256)])]
+# round 6 (the key window): one scene under eight poses of the reference's sampler (depth ranges on either side of and across the
+# binade boundary at 2.0), a scene whose depths span four binades (window too wide for some neighbours: coarse buckets), and one
+# with 14 000 exact duplicates (an oversized bucket whatever the window)
+import math
+prng = np.random.RandomState(11)
+scenes += [scene_inputs(P=20000, size=256, seed=95, lsm=-5.0, h=float(math.pi / 2 + prng.uniform(-1, 1)), v=float(math.pi / 2 + prng.uniform(-0.3, 0.3)),
+                        fov_deg=float(prng.uniform(5, 17))) for _ in range(8)]
+deep = scene_inputs(P=20000, size=256, seed=96, lsm=-5.0)
+deep["means3D"] = (deep["means3D"] * torch.exp(3.0 * torch.rand(20000, 1, generator=torch.Generator().manual_seed(97)))).contiguous()
+dup = scene_inputs(P=40000, size=256, seed=98, lsm=-5.5)
+for k_ in ("means3D", "opacities", "shs", "scales", "rotations"):
+    t_ = dup[k_].clone(); t_[20000:34000] = t_[123]; dup[k_] = t_.contiguous()
+dup["opacities"] = (dup["opacities"] * 0.02).contiguous()
+scenes += [deep, dup]
 same_shape = {}
 for i, d in enumerate(scenes): same_shape.setdefault((d["P"], d["W"], d["H"]), []).append(i)
 oracles = [run_oracle(d) for d in scenes]
