@@ -175,7 +175,7 @@ extern "C" int ggd_set_option(ggd_ctx* ctx, int option, int value) {
   if (option == GGD_OPT_MSD_SORT || option == GGD_OPT_FOLD) {
     // (re)setting the sort options restarts the cross-frame speculation state: the window of recent key ranges, the pause after
     // a miss, the flat-frame streak -- a caller (or a test) that switches forms gets a defined starting point
-    ctx->win_n = 0; ctx->win_pos = 0; ctx->msd_ban = 0; ctx->flat_streak = 0;
+    ctx->win_n = 0; ctx->win_pos = 0; ctx->msd_ban = 0; ctx->msd_oversize_streak = 0; ctx->flat_streak = 0;
   }
   return GGD_OK;
 }
@@ -687,8 +687,11 @@ static int forward_spec_collect(ggd_ctx* ctx, void* stream, const ggd_params* pr
   const bool msd_missed = msd && !ctx->frame_msd_ok;
   const bool msd_oversize = msd_missed && (ctx->frame_msd_flags & 4u) == 0u;   // a bucket above the finish kernel's capacity
   if (msd_oversize) {
-    // the window was too coarse for this data (or the data has > GGD_MSD_CAP equal keys): forget the older frames' ranges and pause
-    ctx->msd_ban = GGD_MSD_BAN;
+    // the window was too coarse for this data -- typically fitted to another scene: forget the older frames' ranges (the window
+    // re-forms from this scene's in GGD_FLAT_STREAK frames) -- or the data has > GGD_MSD_CAP equal keys, which no window cures:
+    // the pause doubles with every consecutive such miss (8, 16, 32, GGD_MSD_BAN frames)
+    ctx->msd_oversize_streak = ctx->msd_oversize_streak < 4 ? ctx->msd_oversize_streak + 1 : 4;
+    ctx->msd_ban = GGD_MSD_BAN >> (4 - ctx->msd_oversize_streak);
     ctx->win_n = 0; ctx->win_pos = 0;
   } else if (msd_missed) {
     ctx->msd_ban = 2;   // a key outside the window: this frame's range joins the window below, the next frames fit again
@@ -698,7 +701,7 @@ static int forward_spec_collect(ggd_ctx* ctx, void* stream, const ggd_params* pr
     ctx->win_pos = (ctx->win_pos + 1) % GGD_MSD_WIN;
     if (ctx->win_n < (1 << 30)) ctx->win_n += 1;
   }
-  if (msd && !msd_missed) ctx->msd_frames += 1;
+  if (msd && !msd_missed) { ctx->msd_frames += 1; ctx->msd_oversize_streak = 0; }
   if (*num_rendered > capacity)
     return ggd_fail(ctx, GGD_E_CAPACITY, "binning_buf capacity is below num_rendered: re-run with a larger buffer");
   if (msd_missed || (spec3 && !ctx->frame_flat)) {   // the short form of the sort did not hold for this frame: bin and blend it again, in full

@@ -66,6 +66,7 @@ struct ggd_ctx {
   bool msd_frame = false;           // this call's front end built the two-launch sort's histograms
   bool frame_msd_ok = false;        // ... and they say the two-launch sort was valid for this frame (read with num_rendered)
   int msd_ban = 0;                  // frames to wait before speculating again after a frame it was not valid for
+  int msd_oversize_streak = 0;      // consecutive oversized-bucket misses: the pause doubles (8, 16, 32, 64 frames) until a frame succeeds
   unsigned long long msd_frames = 0;
   // ... over a speculated KEY WINDOW (round 6): buckets = (key - msd_lo) >> msd_shift, window and shift fitted to the depth
   // keys of the recent folded frames (their min / max arrive with num_rendered), so a depth range that straddles a binade
