@@ -1016,10 +1016,12 @@ int ggd_launch_blend_backward(ggd_ctx* ctx, hipStream_t s, const ggd_params& prm
   int split = ctx->opt[GGD_OPT_BLEND_SPLIT];
   // 4: four INDEPENDENT 8x8 quarter waves per tile (blend_backward_quarter_kernel); any other explicit value: the four
   // quarter waves of a tile in one workgroup, per-record sums combined in LDS (blend_backward_tile_kernel).  1 (auto): the
-  // quarter form from 2048 tiles (8 waves per SIMD to draw from: 1 M / 1024^2 cube 375 -> 333 us, shell 744 -> 565 us), the
-  // tile form below (with 4 waves per SIMD the kernel is one wave's serial chain long, and the quarter form's wave flushes
-  // its sums alone: 500 k / 512^2 184 vs 206 us)
-  if (split == 1) split = T >= 2048 ? 4 : 3;
+  // quarter form.  Until round 6 the rule sent grids below 2048 tiles to the tile form (round 3: 500 k / 512^2 184 vs 206 us);
+  // with the quarter kernel's later changes (whole-record LDS prefetch, live-rectangle pre-cull, flush before the loads) it
+  // is equal or faster on every grid measured -- 100 k / 512^2 54.9 vs 58.5 us, 30 k / 512^2 23.6 vs 24.9, 100 k / 256^2 55 vs 65,
+  // 500 k / 512^2 cube 175 vs 173 (a tie), head-like 500 k / 512^2 (the train step's scenes) 281 vs 394 and 311 vs 484,
+  // 1 M / 704^2 225 vs 250 (profiles/r06/backward_blend_form_ab.txt)
+  if (split == 1) split = 4;
   static const int lds_pad = getenv("GGD_BLEND_BWD_LDS_PAD") ? atoi(getenv("GGD_BLEND_BWD_LDS_PAD")) : 0;   // experiment
   if (split == 4) {
 #define GGD_LAUNCH_BQ(EM, CU)                                                                                             \

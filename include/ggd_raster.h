@@ -227,7 +227,7 @@ enum {
                              debug=1 (key taps) always uses 0 */
   GGD_OPT_BLEND_SPLIT = 3, /* backward blend (the forward always runs four 8x8 quarter waves per tile, one pixel per
                              lane): 3 = the four quarter waves of a tile in one workgroup, per-record sums combined in LDS;
-                             4 = four independent quarter waves per tile; 1 (default) = auto (4 from 2048 tiles, else 3);
+                             4 = four independent quarter waves per tile; 1 (default) = auto (= 4 since round 6: equal or faster on every grid measured);
                              0, 2 = aliases of 3 (the one-wave and two-wave forms they selected were removed).  Backward sums
                              differ only in their fp32 summation order. */
   GGD_OPT_FOLD = 4,       /* single-call forward on the tile-binning path: 1 (default) = the per-Gaussian kernel also builds the
